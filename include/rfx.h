@@ -1,0 +1,92 @@
+/*
+ * rfx.h - C ABI of librfx.so: the gfx950 (MI355X) implementation of riffusion's
+ * spectrogram <-> audio hot path.
+ *
+ * The reference (riffusion-hobby @ v0.3.1, pure Python) has no FFI for this path: its boundary is
+ * the Python class riffusion/spectrogram_converter.py:12-204 whose arithmetic members are four
+ * torchaudio modules.  Each entry point below replaces the torchaudio call named in its comment;
+ * INTEGRATION.md shows the ctypes binding a maintainer adds under that class.
+ *
+ * Conventions: every function returns 0 on success and a negative rfx_status on failure;
+ * rfx_last_error() returns a thread-local message.  All pointers named d_* are DEVICE pointers
+ * (e.g. torch.Tensor.data_ptr()) owned by the caller; `stream` is a hipStream_t passed as void*
+ * (torch.cuda.current_stream().cuda_stream).  No entry point allocates device memory except
+ * rfx_plan_create; scratch space is a caller-provided workspace sized by the *_workspace_bytes
+ * queries.  Plans are immutable after creation and may be shared between threads.
+ *
+ * Layouts: "BFT" is the reference's (batch, n_stft, frames) tensor layout; "slots" is this
+ * library's frame-major stream layout: [batch*frames][rfx_frame_stride()] with every one-sided
+ * bin stored at the position its owning thread streams it from (440 bins are stored twice).
+ */
+#ifndef RFX_H_
+#define RFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rfx_plan rfx_plan;
+
+typedef enum {
+  RFX_OK = 0,
+  RFX_ERR_INVALID = -1,     /* bad argument / unsupported geometry */
+  RFX_ERR_HIP = -2,         /* a HIP runtime call failed */
+  RFX_ERR_WORKSPACE = -3,   /* workspace too small */
+  RFX_ERR_UNSUPPORTED = -4  /* STFT geometry other than n_fft = 40 hop, win = 10 hop, hop = 441 */
+} rfx_status;
+
+/* Mirrors the fields of riffusion/spectrogram_params.py:21-42 that the arithmetic depends on,
+ * already resolved to samples (spectrogram_params.py:62-81). */
+typedef struct {
+  int32_t sample_rate;
+  int32_t n_fft;        /* 17640 */
+  int32_t win_length;   /* 4410  */
+  int32_t hop_length;   /* 441   */
+  int32_t n_mels;       /* num_frequencies */
+  int32_t max_mel_iters;
+} rfx_params;
+
+const char* rfx_last_error(void);
+int rfx_version(void);
+/* number of elements (complex or float) between consecutive frames of a slot-major array */
+int rfx_frame_stride(void);
+int rfx_num_bins(void);
+
+/* Builds the device constants that spectrogram_converter.py:47-99 builds as torchaudio module
+ * buffers: the periodic Hann window (h_window: win_length floats, as torch.hann_window gives it)
+ * and the mel filterbank (h_melfb: n_stft x n_mels floats, torchaudio functional.melscale_fbanks;
+ * may be NULL when no mel entry point will be used). */
+int rfx_plan_create(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
+                    rfx_plan** out_plan);
+int rfx_plan_destroy(rfx_plan* plan);
+
+/* ---- layout converters ------------------------------------------------------------------- */
+/* (B, n_stft, T) float32 magnitudes -> slots (float32) */
+int rfx_pack_magnitudes(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_slots, void* stream);
+/* (B, n_stft, T) complex64 -> slots (complex64); conjugate slots are conjugated */
+int rfx_pack_complex(const rfx_plan* plan, const void* d_bft, int B, int T, void* d_slots, void* stream);
+/* slots (complex64) -> (B, n_stft, T) complex64 */
+int rfx_unpack_complex(const rfx_plan* plan, const void* d_slots, int B, int T, void* d_bft, void* stream);
+
+/* ---- forward: torchaudio.transforms.Spectrogram(power=None) [+ torch.abs] ------------------
+ * spectrogram_converter.py:179 (+ :182).  d_wave: (B, Lw) float32, Lw > n_fft/2.
+ * T = 1 + Lw / hop.  Either output may be NULL. */
+int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mag_slots, void* d_spec_slots,
+             void* stream);
+
+/* ---- inverse: torchaudio.transforms.GriffinLim(n_iter, momentum=0.99, rand_init=True, power=1)
+ * spectrogram_converter.py:62-73, called at :204.
+ * d_mag_slots: magnitudes in slot layout; d_angles0_slots: optional injected initial angles
+ * (NULL = draw U[0,1) real/imag per bin from `seed`); d_wave_out: (B, hop*(T-1)) float32. */
+size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T);
+int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                   int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFX_H_ */

@@ -1,0 +1,262 @@
+// rfx_api.hip - the C ABI of librfx.so (include/rfx.h): plan construction and the host-side drivers
+// that sequence the gfx950 kernels.  No torch types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rfx.h"
+#include "rfx_kernels.h"
+
+using namespace rfx;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define RFX_HIP(call)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return fail(RFX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+}  // namespace
+
+struct rfx_plan {
+  rfx_params p;
+  int device;
+  int num_cus;
+  int n_stft;
+  cf* d_tw1 = nullptr;      // [21][441]
+  cf* d_tw2 = nullptr;      // [21][21]
+  float* d_win = nullptr;   // [4410]
+  float* d_melfb_slots = nullptr;  // [kFrameStride][n_mels]: filterbank rows permuted to slot order
+  float* d_melfb = nullptr;        // [n_stft][n_mels] as given
+};
+
+namespace rfx {
+__global__ void out_scale_kernel(const float* __restrict__ win, float* __restrict__ out, int T, int L) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= L) return;
+  // frames t with 0 <= p - 441 t + 2205 < 4410
+  int tlo = (p + 2205 - (kWin - 1) + kHop - 1) / kHop;  // ceil, numerator may be negative
+  if (p + 2205 - (kWin - 1) < 0) tlo = 0;
+  int thi = (p + 2205) / kHop;
+  if (thi > T - 1) thi = T - 1;
+  float env = 0.f;
+  for (int t = tlo; t <= thi; ++t) {
+    const float w = win[p - kHop * t + 2205];
+    env = fmaf(w, w, env);
+  }
+  out[p] = (2.0f / (float)kNfft) / env;
+}
+}  // namespace rfx
+
+extern "C" {
+
+const char* rfx_last_error(void) { return g_err.c_str(); }
+int rfx_version(void) { return 1; }
+int rfx_frame_stride(void) { return kFrameStride; }
+int rfx_num_bins(void) { return kBins; }
+
+int rfx_plan_create(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
+                    rfx_plan** out_plan) {
+  if (!params || !out_plan || !h_window) return fail(RFX_ERR_INVALID, "rfx_plan_create: null argument");
+  if (params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop)
+    return fail(RFX_ERR_UNSUPPORTED,
+                "rfx_plan_create: only the 44.1 kHz geometry n_fft=17640 win=4410 hop=441 is implemented in HIP");
+  RFX_HIP(hipSetDevice(device));
+  rfx_plan* pl = new rfx_plan();
+  pl->p = *params;
+  pl->device = device;
+  pl->n_stft = params->n_fft / 2 + 1;
+  hipDeviceProp_t prop;
+  RFX_HIP(hipGetDeviceProperties(&prop, device));
+  pl->num_cus = prop.multiProcessorCount;
+
+  const double PI2 = 6.283185307179586476925286766559;
+  std::vector<cf> tw1(21 * kHop), tw2(21 * 21);
+  for (int k1 = 0; k1 < 21; ++k1)
+    for (int n = 0; n < kHop; ++n) {
+      const long long e = ((long long)k1 * (n + 6615)) % kNfft;
+      tw1[k1 * kHop + n] = cf{(float)cos(PI2 * (double)e / kNfft), (float)(-sin(PI2 * (double)e / kNfft))};
+    }
+  for (int i = 0; i < 21; ++i)
+    for (int j = 0; j < 21; ++j) {
+      const int e = (i * j) % kHop;
+      tw2[i * 21 + j] = cf{(float)cos(PI2 * e / (double)kHop), (float)(-sin(PI2 * e / (double)kHop))};
+    }
+  RFX_HIP(hipMalloc(&pl->d_tw1, tw1.size() * sizeof(cf)));
+  RFX_HIP(hipMalloc(&pl->d_tw2, tw2.size() * sizeof(cf)));
+  RFX_HIP(hipMalloc(&pl->d_win, kWin * sizeof(float)));
+  RFX_HIP(hipMemcpy(pl->d_tw1, tw1.data(), tw1.size() * sizeof(cf), hipMemcpyHostToDevice));
+  RFX_HIP(hipMemcpy(pl->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
+  RFX_HIP(hipMemcpy(pl->d_win, h_window, kWin * sizeof(float), hipMemcpyHostToDevice));
+
+  if (h_melfb) {
+    const int M = params->n_mels;
+    if (M <= 0) return fail(RFX_ERR_INVALID, "rfx_plan_create: n_mels must be positive");
+    RFX_HIP(hipMalloc(&pl->d_melfb, (size_t)kBins * M * sizeof(float)));
+    RFX_HIP(hipMemcpy(pl->d_melfb, h_melfb, (size_t)kBins * M * sizeof(float), hipMemcpyHostToDevice));
+    // slot-ordered copy: row of slot position p = filterbank row of its bin for PRIMARY slots, zero for
+    // the 440 duplicate slots and the 3 padding positions, so a GEMM over slot order equals the
+    // reference's GEMM over bins up to summation order
+    std::vector<float> fbs((size_t)kFrameStride * M, 0.f);
+    std::vector<char> seen(kBins, 0);
+    for (int k1 = 0; k1 < 21; ++k1)
+      for (int ka = 0; ka < 21; ++ka)
+        for (int kb = 0; kb < 21; ++kb) {
+          bool cj;
+          const int bin = slot_bin(k1, ka, kb, &cj);
+          if (seen[bin]) continue;
+          seen[bin] = 1;
+          const int pos = slot_pos_f(k1 * 21 + ka, kb);
+          memcpy(&fbs[(size_t)pos * M], &h_melfb[(size_t)bin * M], M * sizeof(float));
+        }
+    RFX_HIP(hipMalloc(&pl->d_melfb_slots, fbs.size() * sizeof(float)));
+    RFX_HIP(hipMemcpy(pl->d_melfb_slots, fbs.data(), fbs.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  *out_plan = pl;
+  return RFX_OK;
+}
+
+int rfx_plan_destroy(rfx_plan* plan) {
+  if (!plan) return RFX_OK;
+  hipFree(plan->d_tw1);
+  hipFree(plan->d_tw2);
+  hipFree(plan->d_win);
+  hipFree(plan->d_melfb);
+  hipFree(plan->d_melfb_slots);
+  delete plan;
+  return RFX_OK;
+}
+
+int rfx_pack_magnitudes(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_slots, void* stream) {
+  if (!plan || !d_lin_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_pack_magnitudes: bad argument");
+  RFX_HIP(launch_pack_mag(d_lin_bft, d_slots, B, T, (hipStream_t)stream));
+  return RFX_OK;
+}
+int rfx_pack_complex(const rfx_plan* plan, const void* d_bft, int B, int T, void* d_slots, void* stream) {
+  if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_pack_complex: bad argument");
+  RFX_HIP(launch_pack_angles((const cf*)d_bft, (cf*)d_slots, B, T, (hipStream_t)stream));
+  return RFX_OK;
+}
+int rfx_unpack_complex(const rfx_plan* plan, const void* d_slots, int B, int T, void* d_bft, void* stream) {
+  if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_unpack_complex: bad argument");
+  RFX_HIP(launch_unpack_complex((const cf*)d_slots, (cf*)d_bft, B, T, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mag_slots, void* d_spec_slots,
+             void* stream) {
+  if (!plan || !d_wave || B <= 0) return fail(RFX_ERR_INVALID, "rfx_stft: bad argument");
+  // torch.stft(center=True, pad_mode="reflect") raises when the pad n_fft/2 is not smaller than the input
+  if (Lw <= kNfft / 2) return fail(RFX_ERR_INVALID, "rfx_stft: reflect padding needs more than n_fft/2 = 8820 samples");
+  StftArgs a;
+  a.wave = d_wave;
+  a.mag = d_mag_slots;
+  a.spec = (cf*)d_spec_slots;
+  a.tw1 = plan->d_tw1;
+  a.tw2 = plan->d_tw2;
+  a.win = plan->d_win;
+  a.B = B;
+  a.Lw = Lw;
+  a.T = 1 + Lw / kHop;
+  const long long frames = (long long)B * a.T;
+  int fpb = (int)((frames + 2LL * plan->num_cus - 1) / (2LL * plan->num_cus));
+  if (fpb < 1) fpb = 1;
+  if (fpb > 16) fpb = 16;
+  a.frames_per_block = fpb;
+  RFX_HIP(launch_stft(a, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+static void gl_layout(int B, int T, size_t& off_tprev, size_t& off_audio, size_t& off_scale, size_t& total, int& Lpad) {
+  const int L = kHop * (T - 1);
+  Lpad = (int)align_up((size_t)L, 64);
+  size_t o = 0;
+  off_tprev = o;
+  o += align_up((size_t)B * T * kFrameStride * sizeof(cf), 256);
+  off_audio = o;
+  o += align_up(4 * (size_t)B * Lpad * sizeof(float), 256);
+  off_scale = o;
+  o += align_up((size_t)Lpad * sizeof(float), 256);
+  total = o;
+}
+
+size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
+  if (!plan || B <= 0 || T < 2) return 0;
+  size_t a, b, c, total;
+  int Lpad;
+  gl_layout(B, T, a, b, c, total, Lpad);
+  return total;
+}
+
+int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                   int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                   void* stream_) {
+  if (!plan || !d_mag_slots || !d_wave_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_griffinlim: null argument");
+  if (B <= 0 || T < 2 || n_iter < 0) return fail(RFX_ERR_INVALID, "rfx_griffinlim: bad shape");
+  if (!(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_griffinlim: momentum must be in [0, 1)");
+  hipStream_t stream = (hipStream_t)stream_;
+  size_t off_tprev, off_audio, off_scale, total;
+  int Lpad;
+  gl_layout(B, T, off_tprev, off_audio, off_scale, total, Lpad);
+  if (workspace_bytes < total) return fail(RFX_ERR_WORKSPACE, "rfx_griffinlim: workspace too small");
+  const int L = kHop * (T - 1);
+  char* ws = (char*)d_workspace;
+  float* audio = (float*)(ws + off_audio);
+  float* bufs[4] = {audio, audio + (size_t)B * Lpad, audio + 2 * (size_t)B * Lpad, audio + 3 * (size_t)B * Lpad};
+  float* scale = (float*)(ws + off_scale);
+
+  hipLaunchKernelGGL(out_scale_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, plan->d_win, scale, T, L);
+  RFX_HIP(hipGetLastError());
+
+  GlArgs g;
+  g.S = d_mag_slots;
+  g.tprev = (cf*)(ws + off_tprev);
+  g.angles0 = (const cf*)d_angles0_slots;
+  g.out_scale = scale;
+  g.tw1 = plan->d_tw1;
+  g.tw2 = plan->d_tw2;
+  g.win = plan->d_win;
+  g.B = B;
+  g.T = T;
+  g.L = L;
+  g.Lpad = Lpad;
+  g.mom = momentum / (1.f + momentum);
+  g.seed = seed;
+  // runs: one resident workgroup per CU (the 74 KB cube and the register budget admit one), every run
+  // at least 10 frames long so that a hop block is shared by at most two runs
+  int nruns = (plan->num_cus + B - 1) / B;
+  if (nruns > T / 10) nruns = T / 10;
+  if (nruns < 1) nruns = 1;
+  g.nruns = nruns;
+  const int nblocks = B * nruns;
+
+  int cur = 0;  // buffers {0,1} or {2,3}
+  g.audio_in[0] = bufs[2];
+  g.audio_in[1] = bufs[3];
+  g.audio_out[0] = bufs[0];
+  g.audio_out[1] = bufs[1];
+  RFX_HIP(launch_gl_iter(0, g, nblocks, stream));
+  for (int it = 1; it <= n_iter; ++it) {
+    g.audio_in[0] = bufs[2 * cur];
+    g.audio_in[1] = bufs[2 * cur + 1];
+    cur ^= 1;
+    g.audio_out[0] = bufs[2 * cur];
+    g.audio_out[1] = bufs[2 * cur + 1];
+    RFX_HIP(launch_gl_iter(it == 1 ? 1 : 2, g, nblocks, stream));
+  }
+  RFX_HIP(launch_gl_combine(bufs[2 * cur], bufs[2 * cur + 1], d_wave_out, B, L, Lpad, stream));
+  return RFX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,307 @@
+// rfx_core.h - per-thread arithmetic of the 17640-point framed transform, written once for both the
+// gfx950 kernels (hipcc) and the host-side phase emulator used by the CPU tests (g++).
+//
+// Geometry (riffusion/spectrogram_params.py:24-27,62-81 at 44.1 kHz): n_fft N = 17640 = 40*441,
+// win_length = 4410 = 10*441 centred in the frame (zero padding 6615 = 15*441 on both sides),
+// hop = 441 = 21*21.  A frame transform (what torch.stft / torch.istft do per frame inside
+// torchaudio's Spectrogram / GriffinLim, spectrogram_converter.py:47-73) is decomposed as
+//
+//   sample index  n = 441*J + n'      J = 15..24 (only the 10 windowed hops are non-zero), n' = 0..440
+//   bin index     k = k1 + 40*k'      k1 = 0..39, k' = 0..440
+//   X[k1+40k'] = sum_{n'} w441^{n'k'} * g(n')^{k1} * sum_{j=0..9} u[441j+n'] * w40^{j*k1}
+//                with g(n') = exp(-2*pi*i*(n'+6615)/17640)
+//
+// i.e. P1: a 40-point DFT of 10 real inputs per n' (only k1 = 0..20 kept: rows 21..39 are complex
+// conjugates because the input is real), a twiddle, then 21 complex 441-point FFTs (rows), each done
+// as 21x21 (P2 over a, twiddle, P3 over b; n' = 21a+b, k' = ka+21kb) with Good-Thomas 3x7 radix-21
+// butterflies.  The 21*441 = 9261 row outputs ("slots") cover the 8821 one-sided bins: slot k<=8820
+// holds X[k]; slot k>8820 holds conj(X[17640-k]) (440 bins with k mod 40 in {0,20} appear twice).
+// Everything between the forward and the inverse transform in Griffin-Lim is per-bin and commutes
+// with conjugation, so slots are treated as independent bins and no mirror exchange is ever needed.
+//
+// The inverse retraces the same three passes backwards (DIF forward / DIT inverse: no reordering
+// between them), ending in a pruned 40-point inverse that yields the 10 windowed hops.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define RFX_HD __host__ __device__ __forceinline__
+#else
+#define RFX_HD inline __attribute__((always_inline))
+#endif
+
+namespace rfx {
+
+struct cf {
+  float re, im;
+};
+
+constexpr int kHop = 441;        // hop_length; also the row length of the 21 x 441 slot matrix
+constexpr int kRows = 21;        // kept k1 residues 0..20
+constexpr int kSlots = 9261;     // 21 * 441
+constexpr int kNfft = 17640;
+constexpr int kWin = 4410;
+constexpr int kBins = 8821;      // n_fft/2 + 1
+constexpr int kFrameStride = 9264;  // slots per frame in HBM, padded so every frame is 128-B aligned
+constexpr int kWinHops = 10;     // win_length / hop
+constexpr int kHalfHops = 5;     // frame t is centred on sample 441*t: it spans hop blocks t-5 .. t+4
+constexpr int kThreads = 448;    // 7 waves x 64; lane 63 of every wave idles (7 x 63 = 441)
+
+RFX_HD cf cmul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// a * conj(b)
+RFX_HD cf cmulc(cf a, cf b) { return cf{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }
+
+// ------------------------------------------------------------------------------------------------
+// Slot <-> HBM position.  A P3 thread q = k1*21 + ka (0..440) owns kb = 0..20.  Complex arrays
+// (tprev, injected angles) are laid out so one lane reads two consecutive kb as 16 bytes and the 63
+// active lanes of a wave read 1008 contiguous bytes; float arrays (|S|) pack four kb per 16 bytes.
+// ------------------------------------------------------------------------------------------------
+RFX_HD int slot_pos_c(int q, int kb) { return kb < 20 ? ((kb >> 1) * kHop + q) * 2 + (kb & 1) : 20 * kHop + q; }
+RFX_HD int slot_pos_f(int q, int kb) { return kb < 20 ? ((kb >> 2) * kHop + q) * 4 + (kb & 3) : 20 * kHop + q; }
+// bin held by slot (k1, ka, kb); *conj_out set when the slot holds the conjugate of that bin
+RFX_HD int slot_bin(int k1, int ka, int kb, bool* conj_out) {
+  int k = k1 + 40 * (ka + 21 * kb);
+  bool c = k > kNfft / 2;
+  if (conj_out) *conj_out = c;
+  return c ? kNfft - k : k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Radix-3 / radix-7 / radix-21 butterflies.  INV selects exp(+i...) kernels.
+// ------------------------------------------------------------------------------------------------
+template <bool INV>
+RFX_HD void dft3(cf& x0, cf& x1, cf& x2) {
+  const float q = INV ? -0.86602540378443864676f : 0.86602540378443864676f;
+  cf s{x1.re + x2.re, x1.im + x2.im};
+  cf d{x1.re - x2.re, x1.im - x2.im};
+  float ar = fmaf(-0.5f, s.re, x0.re), ai = fmaf(-0.5f, s.im, x0.im);
+  x0 = cf{x0.re + s.re, x0.im + s.im};
+  x1 = cf{fmaf(q, d.im, ar), fmaf(-q, d.re, ai)};
+  x2 = cf{fmaf(-q, d.im, ar), fmaf(q, d.re, ai)};
+}
+
+template <bool INV>
+RFX_HD void dft7(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, cf& x5, cf& x6) {
+  constexpr float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+  constexpr float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+  cf p1{x1.re + x6.re, x1.im + x6.im}, m1{x1.re - x6.re, x1.im - x6.im};
+  cf p2{x2.re + x5.re, x2.im + x5.im}, m2{x2.re - x5.re, x2.im - x5.im};
+  cf p3{x3.re + x4.re, x3.im + x4.im}, m3{x3.re - x4.re, x3.im - x4.im};
+  // a_k = x0 + sum_j cos(2 pi j k / 7) p_j ;  b_k = sum_j sin(2 pi j k / 7) m_j
+  cf a1{fmaf(c3, p3.re, fmaf(c2, p2.re, fmaf(c1, p1.re, x0.re))), fmaf(c3, p3.im, fmaf(c2, p2.im, fmaf(c1, p1.im, x0.im)))};
+  cf a2{fmaf(c1, p3.re, fmaf(c3, p2.re, fmaf(c2, p1.re, x0.re))), fmaf(c1, p3.im, fmaf(c3, p2.im, fmaf(c2, p1.im, x0.im)))};
+  cf a3{fmaf(c2, p3.re, fmaf(c1, p2.re, fmaf(c3, p1.re, x0.re))), fmaf(c2, p3.im, fmaf(c1, p2.im, fmaf(c3, p1.im, x0.im)))};
+  cf b1{fmaf(s3, m3.re, fmaf(s2, m2.re, s1 * m1.re)), fmaf(s3, m3.im, fmaf(s2, m2.im, s1 * m1.im))};
+  cf b2{fmaf(-s1, m3.re, fmaf(-s3, m2.re, s2 * m1.re)), fmaf(-s1, m3.im, fmaf(-s3, m2.im, s2 * m1.im))};
+  cf b3{fmaf(s2, m3.re, fmaf(-s1, m2.re, s3 * m1.re)), fmaf(s2, m3.im, fmaf(-s1, m2.im, s3 * m1.im))};
+  x0 = cf{x0.re + p1.re + p2.re + p3.re, x0.im + p1.im + p2.im + p3.im};
+  // forward: X_k = a_k - i b_k, X_{7-k} = a_k + i b_k ; inverse swaps them
+  cf lo1{a1.re + b1.im, a1.im - b1.re}, hi1{a1.re - b1.im, a1.im + b1.re};
+  cf lo2{a2.re + b2.im, a2.im - b2.re}, hi2{a2.re - b2.im, a2.im + b2.re};
+  cf lo3{a3.re + b3.im, a3.im - b3.re}, hi3{a3.re - b3.im, a3.im + b3.re};
+  if (INV) {
+    x1 = hi1; x6 = lo1; x2 = hi2; x5 = lo2; x3 = hi3; x4 = lo3;
+  } else {
+    x1 = lo1; x6 = hi1; x2 = lo2; x5 = hi2; x3 = lo3; x4 = hi3;
+  }
+}
+
+// 21-point DFT, natural order in and out, prime-factor (Good-Thomas) 3 x 7: no internal twiddles.
+//   input  n = (7*n1 + 3*n2) mod 21,   output k = (7*k1 + 15*k2) mod 21
+template <bool INV>
+RFX_HD void dft21(cf (&x)[21]) {
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) dft3<INV>(x[(3 * n2) % 21], x[(7 + 3 * n2) % 21], x[(14 + 3 * n2) % 21]);
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1)
+    dft7<INV>(x[(7 * k1) % 21], x[(7 * k1 + 3) % 21], x[(7 * k1 + 6) % 21], x[(7 * k1 + 9) % 21],
+              x[(7 * k1 + 12) % 21], x[(7 * k1 + 15) % 21], x[(7 * k1 + 18) % 21]);
+  cf y[21];
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) y[(7 * k1 + 15 * k2) % 21] = x[(7 * k1 + 3 * k2) % 21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) x[i] = y[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// 20th / 40th roots of unity as compile-time tables (cos, sin of 2*pi*i/20 and 2*pi*i/40)
+// ------------------------------------------------------------------------------------------------
+#define RFX_C20_TABLE                                                                                       \
+  {1.0f, 0.95105651629515357212f, 0.80901699437494742410f, 0.58778525229247312917f, 0.30901699437494742410f, \
+   0.0f, -0.30901699437494742410f, -0.58778525229247312917f, -0.80901699437494742410f,                      \
+   -0.95105651629515357212f, -1.0f, -0.95105651629515357212f, -0.80901699437494742410f,                     \
+   -0.58778525229247312917f, -0.30901699437494742410f, 0.0f, 0.30901699437494742410f,                       \
+   0.58778525229247312917f, 0.80901699437494742410f, 0.95105651629515357212f}
+#define RFX_S20_TABLE                                                                                       \
+  {0.0f, 0.30901699437494742410f, 0.58778525229247312917f, 0.80901699437494742410f, 0.95105651629515357212f, \
+   1.0f, 0.95105651629515357212f, 0.80901699437494742410f, 0.58778525229247312917f, 0.30901699437494742410f, \
+   0.0f, -0.30901699437494742410f, -0.58778525229247312917f, -0.80901699437494742410f,                      \
+   -0.95105651629515357212f, -1.0f, -0.95105651629515357212f, -0.80901699437494742410f,                     \
+   -0.58778525229247312917f, -0.30901699437494742410f}
+// cos / sin of 2*pi*k/40 for k = 0..10
+#define RFX_C40_TABLE                                                                                       \
+  {1.0f, 0.98768834059513772619f, 0.95105651629515357212f, 0.89100652418836786236f, 0.80901699437494742410f, \
+   0.70710678118654752440f, 0.58778525229247312917f, 0.45399049973954679156f, 0.30901699437494742410f,       \
+   0.15643446504023086901f, 0.0f}
+#define RFX_S40_TABLE                                                                                       \
+  {0.0f, 0.15643446504023086901f, 0.30901699437494742410f, 0.45399049973954679156f, 0.58778525229247312917f, \
+   0.70710678118654752440f, 0.80901699437494742410f, 0.89100652418836786236f, 0.95105651629515357212f,       \
+   0.98768834059513772619f, 1.0f}
+
+// P1 forward: v[k1] = sum_{j=0..9} u[j] * w40^{j*k1}, k1 = 0..20, w40 = exp(-2*pi*i/40), u real.
+// Even/odd split j = 2p+s:  v[k] = E[k] + w40^k O[k],  v[20-k] = conj(E[k] - w40^k O[k]).
+RFX_HD void p1_forward(const float (&u)[10], cf (&v)[21]) {
+  constexpr float C20[20] = RFX_C20_TABLE;
+  constexpr float S20[20] = RFX_S20_TABLE;
+  constexpr float C40[11] = RFX_C40_TABLE;
+  constexpr float S40[11] = RFX_S40_TABLE;
+#pragma unroll
+  for (int k = 0; k <= 10; ++k) {
+    float er = u[0], ei = 0.f, orr = u[1], oi = 0.f;
+#pragma unroll
+    for (int p = 1; p < 5; ++p) {
+      const float c = C20[(p * k) % 20], s = S20[(p * k) % 20];
+      er = fmaf(c, u[2 * p], er);
+      ei = fmaf(-s, u[2 * p], ei);
+      orr = fmaf(c, u[2 * p + 1], orr);
+      oi = fmaf(-s, u[2 * p + 1], oi);
+    }
+    // P = w40^k * O = (c - i s)(or + i oi)
+    const float c = C40[k], s = S40[k];
+    const float pr = fmaf(c, orr, s * oi), pi = fmaf(c, oi, -s * orr);
+    v[k] = cf{er + pr, ei + pi};
+    if (k < 10) v[20 - k] = cf{er - pr, -(ei - pi)};
+  }
+}
+
+// P1 inverse: y[j] = 0.5*(V0.re + (-1)^j V20.re) + sum_{k=1..19} Re(V[k] w40^{-k j}),  j = 0..9
+// (the caller folds the factor 2/N and the synthesis window into one multiplier).
+RFX_HD void p1_inverse(const cf (&V)[21], float (&y)[10]) {
+  constexpr float C20[20] = RFX_C20_TABLE;
+  constexpr float S20[20] = RFX_S20_TABLE;
+  constexpr float C40[11] = RFX_C40_TABLE;
+  constexpr float S40[11] = RFX_S40_TABLE;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    // A[k] = V[k] * w40^{-k s};  B[k] = A[k] + conj(A[20-k]), k = 1..9
+    cf B[10];
+    float a0, a10, a20;
+    if (s == 0) {
+      a0 = V[0].re;
+      a10 = V[10].re;
+      a20 = V[20].re;
+#pragma unroll
+      for (int k = 1; k < 10; ++k) B[k] = cf{V[k].re + V[20 - k].re, V[k].im - V[20 - k].im};
+    } else {
+      a0 = V[0].re;
+      a10 = -V[10].im;  // w40^{-10} = exp(+i*pi/2) = i  ->  Re(i*V10) = -Im(V10)
+      a20 = -V[20].re;  // w40^{-20} = -1
+#pragma unroll
+      for (int k = 1; k < 10; ++k) {
+        // w40^{-k} = C40[k] + i S40[k];  w40^{-(20-k)} = -conj(w40^{-k})... computed directly:
+        const float c = C40[k], sn = S40[k];
+        // A[k] = V[k] * (c + i sn)
+        const float ar = fmaf(c, V[k].re, -sn * V[k].im), ai = fmaf(c, V[k].im, sn * V[k].re);
+        // A[20-k] = V[20-k] * w40^{-(20-k)} = V[20-k] * (-(c - i sn)) = V[20-k] * (-c + i sn)
+        const float br = fmaf(-c, V[20 - k].re, -sn * V[20 - k].im), bi = fmaf(-c, V[20 - k].im, sn * V[20 - k].re);
+        B[k] = cf{ar + br, ai - bi};
+      }
+    }
+    const float h = 0.5f * (a0 + a20);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      float acc = (p & 1) ? h - a10 : h + a10;
+#pragma unroll
+      for (int k = 1; k < 10; ++k) {
+        // Re(B[k] * w20^{-k p}) = B.re cos(2 pi k p/20) - B.im sin(2 pi k p/20)
+        acc = fmaf(C20[(k * p) % 20], B[k].re, acc);
+        acc = fmaf(-S20[(k * p) % 20], B[k].im, acc);
+      }
+      y[2 * p + s] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS "cube" addressing: element (k1, a|ka, b) of the 21 x 21 x 21 work array
+// ------------------------------------------------------------------------------------------------
+RFX_HD int cube_at(int k1, int a, int b) { return (k1 * 21 + a) * 21 + b; }
+
+// P1 store: thread n' = 21a+b twiddles its 21 outputs and scatters them to rows k1
+RFX_HD void p1_store(const cf (&v)[21], const cf (&tw1)[21], cf* cube, int npr) {
+#pragma unroll
+  for (int k1 = 0; k1 < 21; ++k1) cube[k1 * kHop + npr] = (k1 == 0) ? v[0] : cmul(v[k1], tw1[k1]);
+}
+// P1' load: thread n' gathers rows k1 and removes the twiddle
+RFX_HD void p1_load(const cf* cube, const cf (&tw1)[21], cf (&V)[21], int npr) {
+#pragma unroll
+  for (int k1 = 0; k1 < 21; ++k1) {
+    cf x = cube[k1 * kHop + npr];
+    V[k1] = (k1 == 0) ? x : cmulc(x, tw1[k1]);
+  }
+}
+// P2 (forward, in place): thread (k1, b): DFT over a, then twiddle w441^{b*ka}
+RFX_HD void p2_forward(cf* cube, const cf (&tw2)[21], int k1, int b) {
+  cf x[21];
+#pragma unroll
+  for (int a = 0; a < 21; ++a) x[a] = cube[cube_at(k1, a, b)];
+  dft21<false>(x);
+#pragma unroll
+  for (int ka = 0; ka < 21; ++ka) cube[cube_at(k1, ka, b)] = (ka == 0) ? x[0] : cmul(x[ka], tw2[ka]);
+}
+// P2' (inverse, in place): thread (k1, b): inverse DFT over ka
+RFX_HD void p2_inverse(cf* cube, int k1, int b) {
+  cf x[21];
+#pragma unroll
+  for (int ka = 0; ka < 21; ++ka) x[ka] = cube[cube_at(k1, ka, b)];
+  dft21<true>(x);
+#pragma unroll
+  for (int a = 0; a < 21; ++a) cube[cube_at(k1, a, b)] = x[a];
+}
+// P3 (forward): thread (k1, ka): DFT over b -> R[kb] in registers
+RFX_HD void p3_forward(const cf* cube, cf (&R)[21], int k1, int ka) {
+#pragma unroll
+  for (int b = 0; b < 21; ++b) R[b] = cube[cube_at(k1, ka, b)];
+  dft21<false>(R);
+}
+// P3' (inverse): thread (k1, ka): inverse DFT over kb, conj twiddle, store
+RFX_HD void p3_inverse(cf* cube, cf (&Z)[21], const cf (&tw2)[21], int k1, int ka) {
+  dft21<true>(Z);
+#pragma unroll
+  for (int b = 0; b < 21; ++b) cube[cube_at(k1, ka, b)] = (b == 0) ? Z[0] : cmulc(Z[b], tw2[b]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Griffin-Lim per-bin update (torchaudio functional.griffinlim loop body):
+//   angles = rebuilt - m*tprev ; angles /= (|angles| + 1e-16) ; tprev = rebuilt ; next = S*angles
+// ------------------------------------------------------------------------------------------------
+RFX_HD cf gl_update(cf rebuilt, cf tprev, float mom, float S) {
+  const float ar = fmaf(-mom, tprev.re, rebuilt.re), ai = fmaf(-mom, tprev.im, rebuilt.im);
+  const float mag = sqrtf(fmaf(ar, ar, ai * ai));
+  const float sc = S / (mag + 1e-16f);
+  return cf{ar * sc, ai * sc};
+}
+
+// counter-based uniform [0,1) pair for the rand_init of Griffin-Lim (stand-in for torch.rand, whose
+// Philox stream cannot be reproduced bit-for-bit by construction; parity tests inject angles0).
+RFX_HD cf rand_unit_pair(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long z = ctr * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float a = (float)((unsigned)(z >> 40)) * (1.0f / 16777216.0f);
+  const float b = (float)((unsigned)(z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+  return cf{a, b};
+}
+
+// reflect-padded sample index of torch.stft(center=True, pad_mode="reflect"): position p of the
+// un-padded signal of length L
+RFX_HD int reflect_index(int p, int L) {
+  if (p < 0) p = -p;
+  if (p >= L) p = 2 * (L - 1) - p;
+  return p;
+}
+
+}  // namespace rfx

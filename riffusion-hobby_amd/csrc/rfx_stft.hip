@@ -1,0 +1,152 @@
+// rfx_stft.hip - forward framed transform (replaces torchaudio.transforms.Spectrogram(power=None) +
+// torch.abs, riffusion/spectrogram_converter.py:47-59, :179-182) and the layout converters between
+// the reference's (B, n_stft, T) tensors and the slot-major frames the gfx950 kernels stream.
+#include "rfx_frame.hip.h"
+#include "rfx_kernels.h"
+
+namespace rfx {
+
+// ---- inverse of slot_pos_f / slot_pos_c: position inside a frame -> (q, kb)
+__device__ __forceinline__ void pos_f_to_slot(int p, int& q, int& kb) {
+  if (p < 20 * kHop) {
+    const int g = p / (4 * kHop), rem = p - g * 4 * kHop;
+    q = rem >> 2;
+    kb = 4 * g + (rem & 3);
+  } else {
+    q = p - 20 * kHop;
+    kb = 20;
+  }
+}
+__device__ __forceinline__ void pos_c_to_slot(int p, int& q, int& kb) {
+  if (p < 20 * kHop) {
+    const int g = p / (2 * kHop), rem = p - g * 2 * kHop;
+    q = rem >> 1;
+    kb = 2 * g + (rem & 1);
+  } else {
+    q = p - 20 * kHop;
+    kb = 20;
+  }
+}
+
+// one thread per slot position, 16 consecutive frames: reads 64 contiguous bytes of a bin row and
+// writes position-contiguous (coalesced) floats into 16 frames
+template <bool COMPLEX>
+__global__ void __launch_bounds__(256) pack_kernel(const void* __restrict__ src_, void* __restrict__ dst_, int T) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= kSlots) return;
+  const int tchunk = blockIdx.y * 16;
+  const int clip = blockIdx.z;
+  int q, kb;
+  if (COMPLEX) pos_c_to_slot(p, q, kb); else pos_f_to_slot(p, q, kb);
+  bool cj;
+  const int bin = slot_bin(q / 21, q % 21, kb, &cj);
+  const int nt = min(16, T - tchunk);
+  if (COMPLEX) {
+    const cf* src = reinterpret_cast<const cf*>(src_) + ((size_t)clip * kBins + bin) * T + tchunk;
+    cf* dst = reinterpret_cast<cf*>(dst_) + ((size_t)clip * T + tchunk) * kFrameStride + p;
+    for (int i = 0; i < nt; ++i) {
+      cf v = src[i];
+      if (cj) v.im = -v.im;
+      dst[(size_t)i * kFrameStride] = v;
+    }
+  } else {
+    const float* src = reinterpret_cast<const float*>(src_) + ((size_t)clip * kBins + bin) * T + tchunk;
+    float* dst = reinterpret_cast<float*>(dst_) + ((size_t)clip * T + tchunk) * kFrameStride + p;
+    for (int i = 0; i < nt; ++i) dst[(size_t)i * kFrameStride] = src[i];
+  }
+}
+
+// slots -> (B, n_stft, T) complex, reading each bin from its primary slot (test / debugging path)
+__global__ void __launch_bounds__(256) unpack_complex_kernel(const cf* __restrict__ slots, cf* __restrict__ out, int T) {
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= kBins) return;
+  const int tchunk = blockIdx.y * 16;
+  const int clip = blockIdx.z;
+  int k = bin;
+  bool cj = false;
+  if (k % 40 > 20) { k = kNfft - k; cj = true; }
+  const int k1 = k % 40, kp = k / 40;
+  const int ka = kp % 21, kb = kp / 21;
+  const int p = slot_pos_c(k1 * 21 + ka, kb);
+  const int nt = min(16, T - tchunk);
+  for (int i = 0; i < nt; ++i) {
+    cf v = slots[((size_t)clip * T + tchunk + i) * kFrameStride + p];
+    if (cj) v.im = -v.im;
+    out[((size_t)clip * kBins + bin) * T + tchunk + i] = v;
+  }
+}
+
+hipError_t launch_pack_mag(const float* lin_bft, float* S_slots, int B, int T, hipStream_t stream) {
+  dim3 grid((kSlots + 255) / 256, (T + 15) / 16, B);
+  hipLaunchKernelGGL(pack_kernel<false>, grid, dim3(256), 0, stream, (const void*)lin_bft, (void*)S_slots, T);
+  return hipGetLastError();
+}
+hipError_t launch_pack_angles(const cf* ang_bft, cf* slots, int B, int T, hipStream_t stream) {
+  dim3 grid((kSlots + 255) / 256, (T + 15) / 16, B);
+  hipLaunchKernelGGL(pack_kernel<true>, grid, dim3(256), 0, stream, (const void*)ang_bft, (void*)slots, T);
+  return hipGetLastError();
+}
+hipError_t launch_unpack_complex(const cf* slots, cf* out_bft, int B, int T, hipStream_t stream) {
+  dim3 grid((kBins + 255) / 256, (T + 15) / 16, B);
+  hipLaunchKernelGGL(unpack_complex_kernel, grid, dim3(256), 0, stream, slots, out_bft, T);
+  return hipGetLastError();
+}
+
+// ---- forward STFT: frame t of clip b is centred on sample 441*t of the reflect-padded waveform
+__global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* cube = reinterpret_cast<cf*>(smem);
+  const ThreadId t = thread_id();
+  ThreadConst c;
+  load_thread_const(c, t, a.tw1, a.tw2, a.win);
+
+  const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  const int clip = blockIdx.x / chunks;
+  const int f0 = (blockIdx.x - clip * chunks) * a.frames_per_block;
+  const int f1 = min(a.T, f0 + a.frames_per_block);
+  const float* __restrict__ x = a.wave + (size_t)clip * a.Lw;
+
+  for (int fr = f0; fr < f1; ++fr) {
+    float u[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int p = reflect_index((fr + j - kHalfHops) * kHop + t.npr, a.Lw);
+      u[j] = x[p] * c.win[j];
+    }
+    cf R[21];
+    frame_forward(u, R, cube, t, c);
+    const size_t fbase = ((size_t)clip * a.T + fr) * kFrameStride;
+    const int q = t.npr;
+    if (t.active && a.mag) {
+      float m[21];
+#pragma unroll
+      for (int kb = 0; kb < 21; ++kb) m[kb] = sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
+      float4* d4 = reinterpret_cast<float4*>(a.mag + fbase);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) d4[i * kHop + q] = float4{m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]};
+      a.mag[fbase + 20 * kHop + q] = m[20];
+    }
+    if (t.active && a.spec) {
+      float4* d4 = reinterpret_cast<float4*>(a.spec + fbase);
+#pragma unroll
+      for (int i = 0; i < 10; ++i)
+        d4[i * kHop + q] = float4{R[2 * i].re, R[2 * i].im, R[2 * i + 1].re, R[2 * i + 1].im};
+      a.spec[fbase + 20 * kHop + q] = R[20];
+    }
+    __syncthreads();  // the next frame's P1 overwrites rows other waves may still be reading in P3
+  }
+}
+
+hipError_t launch_stft(const StftArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(cf) * kSlots;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  hipLaunchKernelGGL(stft_kernel, dim3(a.B * chunks), dim3(kThreads), lds, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace rfx

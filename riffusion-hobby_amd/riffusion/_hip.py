@@ -1,0 +1,296 @@
+"""
+ctypes binding of librfx.so (include/rfx.h) and the per-`SpectrogramParams` plan cache.
+
+This is the only place where Python touches the native library.  Tensors are handed over as raw
+device pointers (`tensor.data_ptr()`) together with torch's current HIP stream; the library never
+sees a torch type.  If the shared library is missing the import of the HIP path fails loudly -
+there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import threading
+import typing as T
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "librfx.so")
+
+_lib: T.Optional[ctypes.CDLL] = None
+_lib_lock = threading.Lock()
+
+c_void_p, c_int, c_size_t, c_float, c_uint64 = (
+    ctypes.c_void_p,
+    ctypes.c_int,
+    ctypes.c_size_t,
+    ctypes.c_float,
+    ctypes.c_uint64,
+)
+
+
+class RfxParams(ctypes.Structure):
+    """rfx_params of include/rfx.h."""
+
+    _fields_ = [
+        ("sample_rate", ctypes.c_int32),
+        ("n_fft", ctypes.c_int32),
+        ("win_length", ctypes.c_int32),
+        ("hop_length", ctypes.c_int32),
+        ("n_mels", ctypes.c_int32),
+        ("max_mel_iters", ctypes.c_int32),
+    ]
+
+
+class RfxError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol declared in include/rfx.h
+SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
+    "rfx_last_error": (ctypes.c_char_p, []),
+    "rfx_version": (c_int, []),
+    "rfx_frame_stride": (c_int, []),
+    "rfx_num_bins": (c_int, []),
+    "rfx_plan_create": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
+    "rfx_plan_destroy": (c_int, [c_void_p]),
+    "rfx_pack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rfx_pack_complex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rfx_unpack_complex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rfx_stft": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rfx_griffinlim_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "rfx_griffinlim": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+}
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    """Load librfx.so (built by `__graft_entry__.build()` / csrc/build.sh).  Raises if absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise RfxError(
+                    f"{_LIB_PATH} not found: build the HIP library first "
+                    "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+                )
+            lib = ctypes.CDLL(_LIB_PATH)
+            for name, (restype, argtypes) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the .so does not export it
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = lib
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load_library().rfx_last_error()
+        raise RfxError(f"librfx error {status}: {msg.decode() if msg else '?'}")
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------
+# Host-side constants, built with the same torch ops torchaudio uses so that they are bit-identical
+# to the buffers of the reference's modules (spectrogram_converter.py:47-99)
+# ------------------------------------------------------------------------------------------------
+
+
+def hann_window(win_length: int) -> torch.Tensor:
+    return torch.hann_window(win_length, periodic=True, dtype=torch.float32)
+
+
+def _hz_to_mel(freq: float, mel_scale: str) -> float:
+    if mel_scale == "htk":
+        return 2595.0 * math.log10(1.0 + freq / 700.0)
+    # slaney
+    f_sp = 200.0 / 3
+    if freq >= 1000.0:
+        return 1000.0 / f_sp + math.log(freq / 1000.0) / (math.log(6.4) / 27.0)
+    return freq / f_sp
+
+
+def _mel_to_hz(mels: torch.Tensor, mel_scale: str) -> torch.Tensor:
+    if mel_scale == "htk":
+        return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    f_sp = 200.0 / 3
+    freqs = f_sp * mels
+    min_log_mel = 1000.0 / f_sp
+    logstep = math.log(6.4) / 27.0
+    is_log = mels >= min_log_mel
+    freqs[is_log] = 1000.0 * torch.exp(logstep * (mels[is_log] - min_log_mel))
+    return freqs
+
+
+def mel_filterbank(
+    n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int, norm: T.Optional[str], mel_scale: str
+) -> torch.Tensor:
+    """Triangular mel filterbank (n_freqs, n_mels), the buffer of torchaudio's MelScale/InverseMelScale."""
+    if norm is not None and norm != "slaney":
+        raise ValueError('norm must be one of None or "slaney"')
+    if mel_scale not in ("htk", "slaney"):
+        raise ValueError('mel_scale should be one of "htk" or "slaney".')
+    grid = torch.linspace(0, sample_rate // 2, n_freqs)
+    mel_pts = torch.linspace(_hz_to_mel(f_min, mel_scale), _hz_to_mel(f_max, mel_scale), n_mels + 2)
+    hz_pts = _mel_to_hz(mel_pts, mel_scale)
+    widths = hz_pts[1:] - hz_pts[:-1]
+    dist = hz_pts.unsqueeze(0) - grid.unsqueeze(1)
+    falling = (-1.0 * dist[:, :-2]) / widths[:-1]
+    rising = dist[:, 2:] / widths[1:]
+    fb = torch.max(torch.zeros(1), torch.min(falling, rising))
+    if norm == "slaney":
+        fb = fb * (2.0 / (hz_pts[2 : n_mels + 2] - hz_pts[:n_mels])).unsqueeze(0)
+    return fb.to(torch.float32).contiguous()
+
+
+class Plan:
+    """Owns one rfx_plan (device constants for one parameter set on one device)."""
+
+    def __init__(self, params: T.Any, device: torch.device):
+        self.lib = load_library()
+        self.device = device
+        self.n_fft, self.win_length, self.hop_length = params.n_fft, params.win_length, params.hop_length
+        self.n_stft = self.n_fft // 2 + 1
+        self.n_mels = params.num_frequencies
+        self.window = hann_window(self.win_length)
+        self.melfb = mel_filterbank(
+            self.n_stft,
+            float(params.min_frequency),
+            float(params.max_frequency),
+            self.n_mels,
+            params.sample_rate,
+            params.mel_scale_norm,
+            params.mel_scale_type,
+        )
+        cp = RfxParams(params.sample_rate, self.n_fft, self.win_length, self.hop_length, self.n_mels, params.max_mel_iters)
+        handle = c_void_p()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        check(
+            self.lib.rfx_plan_create(
+                ctypes.byref(cp), self.window.data_ptr(), self.melfb.data_ptr(), index, ctypes.byref(handle)
+            )
+        )
+        self.handle = handle
+        self.frame_stride = self.lib.rfx_frame_stride()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.rfx_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- thin typed wrappers -----------------------------------------------------------------
+    def _chk(self, t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        if t.device.type != "cuda":
+            raise RfxError("HIP path needs tensors on the GPU")
+        return t.to(dtype).contiguous()
+
+    def pack_magnitudes(self, lin_bft: torch.Tensor) -> torch.Tensor:
+        lin_bft = self._chk(lin_bft, torch.float32)
+        B, F, Tn = lin_bft.shape
+        if F != self.n_stft:
+            raise ValueError(f"expected {self.n_stft} linear bins, got {F}")
+        out = torch.zeros((B * Tn, self.frame_stride), dtype=torch.float32, device=lin_bft.device)
+        check(self.lib.rfx_pack_magnitudes(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        return out
+
+    def pack_complex(self, x_bft: torch.Tensor) -> torch.Tensor:
+        x_bft = self._chk(x_bft, torch.complex64)
+        B, F, Tn = x_bft.shape
+        out = torch.zeros((B * Tn, self.frame_stride), dtype=torch.complex64, device=x_bft.device)
+        check(self.lib.rfx_pack_complex(self.handle, x_bft.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        return out
+
+    def unpack_complex(self, slots: torch.Tensor, B: int, Tn: int) -> torch.Tensor:
+        out = torch.empty((B, self.n_stft, Tn), dtype=torch.complex64, device=slots.device)
+        check(self.lib.rfx_unpack_complex(self.handle, slots.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        return out
+
+    def stft(self, wave: torch.Tensor, want_mag: bool, want_spec: bool):
+        wave = self._chk(wave, torch.float32)
+        B, Lw = wave.shape
+        if Lw <= self.n_fft // 2:
+            # same condition under which torch.stft(pad_mode="reflect") raises in the reference
+            raise RuntimeError(
+                f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                f"but got: padding ({self.n_fft // 2}, {self.n_fft // 2}) at dimension 2 of input {list(wave.shape)}"
+            )
+        Tn = 1 + Lw // self.hop_length
+        mag = torch.empty((B * Tn, self.frame_stride), dtype=torch.float32, device=wave.device) if want_mag else None
+        spec = torch.empty((B * Tn, self.frame_stride), dtype=torch.complex64, device=wave.device) if want_spec else None
+        check(
+            self.lib.rfx_stft(
+                self.handle,
+                wave.data_ptr(),
+                B,
+                Lw,
+                mag.data_ptr() if mag is not None else None,
+                spec.data_ptr() if spec is not None else None,
+                current_stream(),
+            )
+        )
+        return mag, spec, Tn
+
+    def griffinlim(
+        self,
+        mag_slots: torch.Tensor,
+        B: int,
+        Tn: int,
+        n_iter: int,
+        momentum: float = 0.99,
+        angles0_slots: T.Optional[torch.Tensor] = None,
+        seed: int = 0,
+        workspace: T.Optional[torch.Tensor] = None,
+    ) -> torch.Tensor:
+        need = self.lib.rfx_griffinlim_workspace_bytes(self.handle, B, Tn)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=mag_slots.device)
+        out = torch.empty((B, self.hop_length * (Tn - 1)), dtype=torch.float32, device=mag_slots.device)
+        check(
+            self.lib.rfx_griffinlim(
+                self.handle,
+                mag_slots.data_ptr(),
+                angles0_slots.data_ptr() if angles0_slots is not None else None,
+                seed & 0xFFFFFFFFFFFFFFFF,
+                B,
+                Tn,
+                n_iter,
+                momentum,
+                out.data_ptr(),
+                workspace.data_ptr(),
+                workspace.numel(),
+                current_stream(),
+            )
+        )
+        return out
+
+
+_plans: T.Dict[T.Tuple[T.Any, str], Plan] = {}
+_plans_lock = threading.Lock()
+
+
+def get_plan(params: T.Any, device: T.Union[str, torch.device]) -> Plan:
+    """Plans are immutable and cached per (frozen params, device): constructing a converter per
+    request, as the reference's server does (server.py:159), costs a dictionary lookup."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RfxError("the HIP path runs on the GPU only (device 'cuda'); there is no CPU implementation")
+    key = (params, str(dev))
+    with _plans_lock:
+        plan = _plans.get(key)
+        if plan is None:
+            plan = Plan(params, dev)
+            _plans[key] = plan
+    return plan
