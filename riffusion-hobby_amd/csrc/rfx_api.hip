@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -233,9 +234,12 @@ int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d
   g.Lpad = Lpad;
   g.mom = momentum / (1.f + momentum);
   g.seed = seed;
-  // runs: one resident workgroup per CU (the 74 KB cube and the register budget admit one), every run
-  // at least 10 frames long so that a hop block is shared by at most two runs
-  int nruns = (plan->num_cus + B - 1) / B;
+  g.timing = nullptr;
+  if (const char* e = getenv("RFX_TIMING_PTR")) g.timing = (unsigned long long*)strtoull(e, nullptr, 0);
+  // runs: fill every resident workgroup slot of the chip once; every run at least 10 frames long so
+  // that a hop block is shared by at most two runs
+  const int slots = plan->num_cus * gl_blocks_per_cu();
+  int nruns = (slots + B - 1) / B;
   if (nruns > T / 10) nruns = T / 10;
   if (nruns < 1) nruns = 1;
   g.nruns = nruns;

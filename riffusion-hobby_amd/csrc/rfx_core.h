@@ -42,7 +42,8 @@ constexpr int kSlots = 9261;     // 21 * 441
 constexpr int kNfft = 17640;
 constexpr int kWin = 4410;
 constexpr int kBins = 8821;      // n_fft/2 + 1
-constexpr int kFrameStride = 9264;  // slots per frame in HBM, padded so every frame is 128-B aligned
+constexpr int kQPad = 448;          // 441 owner threads padded to 7 waves x 64 lanes in HBM
+constexpr int kFrameStride = 9408;  // 21 * 448 positions per frame in HBM: every wave-load is whole 128-B lines
 constexpr int kWinHops = 10;     // win_length / hop
 constexpr int kHalfHops = 5;     // frame t is centred on sample 441*t: it spans hop blocks t-5 .. t+4
 constexpr int kThreads = 448;    // 7 waves x 64; lane 63 of every wave idles (7 x 63 = 441)
@@ -52,12 +53,45 @@ RFX_HD cf cmul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.re * b.im + 
 RFX_HD cf cmulc(cf a, cf b) { return cf{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }
 
 // ------------------------------------------------------------------------------------------------
-// Slot <-> HBM position.  A P3 thread q = k1*21 + ka (0..440) owns kb = 0..20.  Complex arrays
-// (tprev, injected angles) are laid out so one lane reads two consecutive kb as 16 bytes and the 63
-// active lanes of a wave read 1008 contiguous bytes; float arrays (|S|) pack four kb per 16 bytes.
+// Slot <-> HBM position.  A P3 thread q = k1*21 + ka (0..440) owns kb = 0..20; in memory it sits
+// at qp = (q/63)*64 + q%63 = its threadIdx (7 waves x 63 active lanes, lane 63 is padding), so that
+// one wave-wide 16-B-per-lane access covers exactly eight whole 128-B lines.  Complex arrays
+// (tprev, injected angles) hold two consecutive kb per 16 bytes, float arrays (|S|) four.
 // ------------------------------------------------------------------------------------------------
-RFX_HD int slot_pos_c(int q, int kb) { return kb < 20 ? ((kb >> 1) * kHop + q) * 2 + (kb & 1) : 20 * kHop + q; }
-RFX_HD int slot_pos_f(int q, int kb) { return kb < 20 ? ((kb >> 2) * kHop + q) * 4 + (kb & 3) : 20 * kHop + q; }
+RFX_HD int slot_qp(int q) { return q + q / 63; }
+RFX_HD int slot_pos_c(int q, int kb) {
+  return kb < 20 ? ((kb >> 1) * kQPad + slot_qp(q)) * 2 + (kb & 1) : 20 * kQPad + slot_qp(q);
+}
+RFX_HD int slot_pos_f(int q, int kb) {
+  return kb < 20 ? ((kb >> 2) * kQPad + slot_qp(q)) * 4 + (kb & 3) : 20 * kQPad + slot_qp(q);
+}
+// inverse maps: position -> (q, kb); returns false for padding positions
+RFX_HD bool pos_c_to_slot(int p, int& q, int& kb) {
+  int qp;
+  if (p < 20 * kQPad) {
+    const int g = p / (2 * kQPad), rem = p - g * 2 * kQPad;
+    qp = rem >> 1;
+    kb = 2 * g + (rem & 1);
+  } else {
+    qp = p - 20 * kQPad;
+    kb = 20;
+  }
+  q = (qp >> 6) * 63 + (qp & 63);
+  return (qp & 63) != 63;
+}
+RFX_HD bool pos_f_to_slot(int p, int& q, int& kb) {
+  int qp;
+  if (p < 20 * kQPad) {
+    const int g = p / (4 * kQPad), rem = p - g * 4 * kQPad;
+    qp = rem >> 2;
+    kb = 4 * g + (rem & 3);
+  } else {
+    qp = p - 20 * kQPad;
+    kb = 20;
+  }
+  q = (qp >> 6) * 63 + (qp & 63);
+  return (qp & 63) != 63;
+}
 // bin held by slot (k1, ka, kb); *conj_out set when the slot holds the conjugate of that bin
 RFX_HD int slot_bin(int k1, int ka, int kb, bool* conj_out) {
   int k = k1 + 40 * (ka + 21 * kb);
@@ -229,27 +263,38 @@ RFX_HD void p1_inverse(const cf (&V)[21], float (&y)[10]) {
 // ------------------------------------------------------------------------------------------------
 RFX_HD int cube_at(int k1, int a, int b) { return (k1 * 21 + a) * 21 + b; }
 
+// Twiddles are passed as accessors `tw(i) -> cf` so that the kernels can stream them from a table
+// (L2 / LDS) exactly where they are consumed instead of pinning 42 registers per table, while the
+// host emulator indexes plain arrays.  RFX_SCHED_FENCE() marks the points the device compiler must
+// not schedule across (it bounds how many table loads are in flight, i.e. the register pressure).
+#ifndef RFX_SCHED_FENCE
+#define RFX_SCHED_FENCE() ((void)0)
+#endif
+
 // P1 store: thread n' = 21a+b twiddles its 21 outputs and scatters them to rows k1
-RFX_HD void p1_store(const cf (&v)[21], const cf (&tw1)[21], cf* cube, int npr) {
+template <class TW>
+RFX_HD void p1_store(const cf (&v)[21], TW tw1, cf* cube, int npr) {
+  cube[npr] = v[0];
 #pragma unroll
-  for (int k1 = 0; k1 < 21; ++k1) cube[k1 * kHop + npr] = (k1 == 0) ? v[0] : cmul(v[k1], tw1[k1]);
+  for (int k1 = 1; k1 < 21; ++k1) cube[k1 * kHop + npr] = cmul(v[k1], tw1(k1));
 }
 // P1' load: thread n' gathers rows k1 and removes the twiddle
-RFX_HD void p1_load(const cf* cube, const cf (&tw1)[21], cf (&V)[21], int npr) {
+template <class TW>
+RFX_HD void p1_load(const cf* cube, TW tw1, cf (&V)[21], int npr) {
+  V[0] = cube[npr];
 #pragma unroll
-  for (int k1 = 0; k1 < 21; ++k1) {
-    cf x = cube[k1 * kHop + npr];
-    V[k1] = (k1 == 0) ? x : cmulc(x, tw1[k1]);
-  }
+  for (int k1 = 1; k1 < 21; ++k1) V[k1] = cmulc(cube[k1 * kHop + npr], tw1(k1));
 }
 // P2 (forward, in place): thread (k1, b): DFT over a, then twiddle w441^{b*ka}
-RFX_HD void p2_forward(cf* cube, const cf (&tw2)[21], int k1, int b) {
+template <class TW>
+RFX_HD void p2_forward(cf* cube, TW tw2, int k1, int b) {
   cf x[21];
 #pragma unroll
   for (int a = 0; a < 21; ++a) x[a] = cube[cube_at(k1, a, b)];
   dft21<false>(x);
+  cube[cube_at(k1, 0, b)] = x[0];
 #pragma unroll
-  for (int ka = 0; ka < 21; ++ka) cube[cube_at(k1, ka, b)] = (ka == 0) ? x[0] : cmul(x[ka], tw2[ka]);
+  for (int ka = 1; ka < 21; ++ka) cube[cube_at(k1, ka, b)] = cmul(x[ka], tw2(ka));
 }
 // P2' (inverse, in place): thread (k1, b): inverse DFT over ka
 RFX_HD void p2_inverse(cf* cube, int k1, int b) {
@@ -267,10 +312,12 @@ RFX_HD void p3_forward(const cf* cube, cf (&R)[21], int k1, int ka) {
   dft21<false>(R);
 }
 // P3' (inverse): thread (k1, ka): inverse DFT over kb, conj twiddle, store
-RFX_HD void p3_inverse(cf* cube, cf (&Z)[21], const cf (&tw2)[21], int k1, int ka) {
+template <class TW>
+RFX_HD void p3_inverse(cf* cube, cf (&Z)[21], TW tw2, int k1, int ka) {
   dft21<true>(Z);
+  cube[cube_at(k1, ka, 0)] = Z[0];
 #pragma unroll
-  for (int b = 0; b < 21; ++b) cube[cube_at(k1, ka, b)] = (b == 0) ? Z[0] : cmulc(Z[b], tw2[b]);
+  for (int b = 1; b < 21; ++b) cube[cube_at(k1, ka, b)] = cmulc(Z[b], tw2(b));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -279,8 +326,15 @@ RFX_HD void p3_inverse(cf* cube, cf (&Z)[21], const cf (&tw2)[21], int k1, int k
 // ------------------------------------------------------------------------------------------------
 RFX_HD cf gl_update(cf rebuilt, cf tprev, float mom, float S) {
   const float ar = fmaf(-mom, tprev.re, rebuilt.re), ai = fmaf(-mom, tprev.im, rebuilt.im);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sqrt / divide expansions (~10 VALU
+  // instructions per bin); the difference is below the fp32 noise Griffin-Lim amplifies anyway
+  const float mag = __builtin_amdgcn_sqrtf(fmaf(ar, ar, ai * ai));
+  const float sc = S * __builtin_amdgcn_rcpf(mag + 1e-16f);
+#else
   const float mag = sqrtf(fmaf(ar, ar, ai * ai));
   const float sc = S / (mag + 1e-16f);
+#endif
   return cf{ar * sc, ai * sc};
 }
 

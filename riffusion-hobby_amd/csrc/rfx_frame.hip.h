@@ -1,56 +1,103 @@
 // rfx_frame.hip.h - device-side frame engine shared by the Griffin-Lim and the forward STFT kernels.
 //
 // One workgroup = 7 waves (448 threads, lane 63 of each wave idle) owns one frame at a time and
-// keeps the 21 x 441 complex slot matrix ("cube", 74 088 B) in LDS.  Thread roles by pass:
+// keeps the 21 x 441 complex slot matrix ("cube", 74 088 B) in LDS, followed by the 21 x 21 table
+// of w441 twiddles (3 528 B): 77 616 B per workgroup, so two workgroups share a CU's 160 KiB and
+// one's LDS-exchange / HBM phases overlap the other's butterflies.  Thread roles by pass:
 //   P1 / P1' : n' = wave*63 + lane             (a = n'/21 = wave*3 + lane/21, b = lane%21)
 //   P2 / P2' : (k1, b)  with k1 = wave*3 + lane/21, b  = lane%21
 //   P3 / P3' : (k1, ka) with k1 = wave*3 + lane/21, ka = lane%21
 // so a thread keeps the same (row-triple, idx) identity throughout; the P2<->P3 exchange stays
 // inside a wave's three rows and only the P1<->P2 exchange crosses waves (one barrier each way).
+// Register budget is 128 VGPRs (4 waves per SIMD): the g(n')^k1 twiddles stream from their
+// L2-resident table at the point of use, the w441 twiddles from LDS.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#define RFX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #include "rfx_core.h"
 
 namespace rfx {
 
 using v4f = float __attribute__((ext_vector_type(4)));
 using v2f = float __attribute__((ext_vector_type(2)));
+using v4u = unsigned __attribute__((ext_vector_type(4)));
+using v2u = unsigned __attribute__((ext_vector_type(2)));
+
+// ---- buffer-descriptor addressing: every global access is  SRD (SGPRs, wave-uniform)  +  one 32-bit
+// per-lane byte offset  +  a scalar byte offset, so no 64-bit per-lane address ever occupies VGPRs.
+// Descriptors are built only from kernel arguments and blockIdx, which keeps them provably uniform.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int kAuxNT = 2;  // gfx950 cache-policy bit "nt": streamed once, do not keep in L2
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), 0x00020000);
+}
+template <int AUX = 0>
+__device__ __forceinline__ float ld1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+}
+template <int AUX = 0>
+__device__ __forceinline__ v2f ld2(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+}
+template <int AUX = 0>
+__device__ __forceinline__ v4f ld4(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+template <int AUX = 0>
+__device__ __forceinline__ void st1(float v, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void st2(v2f v, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void st4(v4f v, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff, soff, AUX);
+}
+
+constexpr int kCubeBytes = kSlots * (int)sizeof(cf);        // 74 088
+constexpr int kTw2Bytes = 21 * 21 * (int)sizeof(cf);        // 3 528
+constexpr int kFrameLdsBytes = kCubeBytes + kTw2Bytes;      // 77 616
 
 struct ThreadId {
-  int wave, lane, row3, idx;  // row3 = lane/21 (0..2), idx = lane%21
-  int npr;                    // P1 index n' (== P3 index q = k1*21+ka)
-  int k1;                     // row owned in P2/P3
+  int idx;   // lane % 21
+  int npr;   // P1 index n' (== P3 index q = k1*21+ka)
+  int k1;    // row owned in P2/P3
   bool active;
 };
 
 __device__ __forceinline__ ThreadId thread_id() {
   ThreadId t;
-  t.wave = threadIdx.x >> 6;
-  t.lane = threadIdx.x & 63;
-  t.active = t.lane < 63;
-  const int l = t.active ? t.lane : 62;  // idle lane shadows lane 62 (loads only, never stores)
-  t.row3 = l / 21;
-  t.idx = l - 21 * t.row3;
-  t.k1 = t.wave * 3 + t.row3;
-  t.npr = t.wave * 63 + l;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  t.active = lane < 63;
+  const int l = t.active ? lane : 62;  // idle lane shadows lane 62 (loads only, never stores)
+  const int row3 = l / 21;
+  t.idx = l - 21 * row3;
+  t.k1 = wave * 3 + row3;
+  t.npr = wave * 63 + l;
   return t;
 }
 
-// per-thread constants that live in registers for the whole run of frames
-struct ThreadConst {
-  cf tw1[21];     // g(n')^k1
-  cf tw2[21];     // w441^(idx*i)
-  float win[10];  // hann[441*j + n']
+struct FrameCtx {
+  cf* cube;          // LDS
+  const cf* tw2s;    // LDS copy of tw2, [i][idx]
+  rsrc_t tw1;        // global tw1[21][441]
+  unsigned npr8;     // n' * sizeof(cf)
 };
 
-__device__ __forceinline__ void load_thread_const(ThreadConst& c, const ThreadId& t, const cf* __restrict__ tw1,
-                                                  const cf* __restrict__ tw2, const float* __restrict__ win) {
-#pragma unroll
-  for (int k = 0; k < 21; ++k) c.tw1[k] = tw1[k * kHop + t.npr];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) c.tw2[k] = tw2[k * 21 + t.idx];
-#pragma unroll
-  for (int j = 0; j < 10; ++j) c.win[j] = win[j * kHop + t.npr];
+// copies the w441 table into LDS; the caller must barrier before the first transform
+__device__ __forceinline__ FrameCtx frame_ctx(char* smem, const ThreadId& t, const cf* __restrict__ tw1,
+                                              const cf* __restrict__ tw2) {
+  FrameCtx f;
+  f.cube = reinterpret_cast<cf*>(smem);
+  cf* s = reinterpret_cast<cf*>(smem + kCubeBytes);
+  if (threadIdx.x < 441) s[threadIdx.x] = tw2[threadIdx.x];
+  f.tw2s = s + t.idx;
+  f.tw1 = make_rsrc(tw1, 21 * kHop * sizeof(cf));
+  f.npr8 = (unsigned)t.npr * 8u;
+  return f;
 }
 
 // wave-private LDS hand-off (P2 <-> P3 touch only the wave's own three rows).  DS operations of one
@@ -68,27 +115,63 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
-// forward transform of one frame: u[10] (windowed samples of thread n') -> R[21] (slots of thread q)
-__device__ __forceinline__ void frame_forward(const float (&u)[10], cf (&R)[21], cf* cube, const ThreadId& t,
-                                              const ThreadConst& c) {
-  cf v[21];
-  p1_forward(u, v);
-  if (t.active) p1_store(v, c.tw1, cube, t.npr);
+// the 20 non-trivial g(n')^k1 twiddles of this thread, fetched from the L2-resident table in one
+// burst so that their latency overlaps the butterflies / the barrier that precede their use
+struct Tw1 {
+  cf w[21];
+};
+__device__ __forceinline__ void load_tw1(Tw1& tw, const FrameCtx& f) {
+#pragma unroll
+  for (int k = 1; k < 21; ++k) {
+    v2f w = ld2(f.tw1, f.npr8, (unsigned)k * (kHop * 8u));
+    tw.w[k] = cf{w.x, w.y};
+  }
+}
+
+// forward transform of one frame: u[10] (windowed samples of thread n') -> R[21] (slots of thread q).
+// `after_barrier()` runs right after the cross-wave barrier: the caller uses it to put HBM loads in
+// flight underneath P2/P3.
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <class Hook, class Pre = NoHook>
+__device__ __forceinline__ void frame_forward(const float (&u)[10], cf (&R)[21], const FrameCtx& f, const ThreadId& t,
+                                              Hook after_barrier, Pre before_barrier = Pre()) {
+  {
+    Tw1 tw;
+    load_tw1(tw, f);
+    cf v[21];
+    p1_forward(u, v);
+    if (t.active) p1_store(v, [&tw](int k) { return tw.w[k]; }, f.cube, t.npr);
+  }
+  before_barrier();
   __syncthreads();
-  if (t.active) p2_forward(cube, c.tw2, t.k1, t.idx);
+  after_barrier();
+  {
+    const cf* tw = f.tw2s;
+    if (t.active) p2_forward(f.cube, [tw](int k) { return tw[k * 21]; }, t.k1, t.idx);
+  }
   wave_sync();
-  p3_forward(cube, R, t.k1, t.idx);
+  p3_forward(f.cube, R, t.k1, t.idx);
 }
 
 // inverse transform of one frame: Z[21] (slots of thread q) -> y[10] (un-normalised hops of thread n')
-__device__ __forceinline__ void frame_inverse(cf (&Z)[21], float (&y)[10], cf* cube, const ThreadId& t,
-                                              const ThreadConst& c) {
-  if (t.active) p3_inverse(cube, Z, c.tw2, t.k1, t.idx);
+template <class Pre = NoHook, class Post = NoHook>
+__device__ __forceinline__ void frame_inverse(cf (&Z)[21], float (&y)[10], const FrameCtx& f, const ThreadId& t,
+                                              Pre before_barrier = Pre(), Post after_barrier = Post()) {
+  {
+    const cf* tw = f.tw2s;
+    if (t.active) p3_inverse(f.cube, Z, [tw](int k) { return tw[k * 21]; }, t.k1, t.idx);
+  }
   wave_sync();
-  if (t.active) p2_inverse(cube, t.k1, t.idx);
+  if (t.active) p2_inverse(f.cube, t.k1, t.idx);
+  Tw1 tw;
+  load_tw1(tw, f);  // in flight across the barrier
+  before_barrier();
   __syncthreads();
+  after_barrier();
   cf V[21];
-  p1_load(cube, c.tw1, V, t.npr);
+  p1_load(f.cube, [&tw](int k) { return tw.w[k]; }, V, t.npr);
   p1_inverse(V, y);
 }
 

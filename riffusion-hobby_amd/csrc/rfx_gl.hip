@@ -15,17 +15,102 @@
 // for 8821 bins) = the (20n+4)*F*T formulation of SURVEY.md 8(d); `angles` never exists in memory.
 #include "rfx_frame.hip.h"
 #include "rfx_kernels.h"
+#include <stdlib.h>
 
 namespace rfx {
 
-template <int MODE>
-__global__ void __launch_bounds__(kThreads) gl_iter_kernel(GlArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  cf* cube = reinterpret_cast<cf*>(smem);
+#ifndef RFX_MIN_WAVES
+#define RFX_MIN_WAVES 4
+#endif
 
+// descriptors of the per-clip streams (wave-uniform, live in SGPRs)
+struct GlStreams {
+  rsrc_t S, tprev, init;  // this clip's slot-major frames
+  bool have_init;
+};
+
+#ifndef RFX_STREAM_AUX
+#define RFX_STREAM_AUX 2  // gfx950 'nt'
+#endif
+// The per-bin update streams |S| (4 B) and tprev (8 B) per slot from HBM.  A thread's 21 slots are
+// fetched in three stages whose loads are put in flight well ahead of their use (stage A under
+// P2/P3, stage B under A's arithmetic, stage C under B's), each stage costing 24 / 24 / 15 VGPRs:
+//   A: kb 0..7   B: kb 8..15   C: kb 16..20
+template <int KB0, int N>
+struct Stage {
+  static constexpr int kNS4 = N / 4, kNT4 = N / 2;  // 16-B loads of |S| and of tprev
+  v4f s4[kNS4 > 0 ? kNS4 : 1];
+  v4f t4[kNT4 > 0 ? kNT4 : 1];
+  float s_tail;  // kb 20 (only when KB0 + N == 21)
+  v2f t_tail;
+};
+
+template <int MODE, int KB0, int N>
+__device__ __forceinline__ void stage_issue(Stage<KB0, N>& g, const GlStreams& st, unsigned foff, unsigned q) {
+  constexpr int NB = (KB0 + N == 21) ? N - 1 : N;  // kb handled by 16-B loads
+#pragma unroll
+  for (int i = 0; i < NB / 4; ++i) g.s4[i] = ld4<RFX_STREAM_AUX>(st.S, q * 16u, foff + (unsigned)(KB0 / 4 + i) * (kQPad * 16u));
+  if (KB0 + N == 21) g.s_tail = ld1<RFX_STREAM_AUX>(st.S, q * 4u, foff + 20u * kQPad * 4u);
+  if (MODE == 2 || (MODE == 0 && st.have_init)) {
+    const rsrc_t src = (MODE == 0) ? st.init : st.tprev;
+#pragma unroll
+    for (int i = 0; i < NB / 2; ++i) g.t4[i] = ld4<RFX_STREAM_AUX>(src, q * 16u, 2u * foff + (unsigned)(KB0 / 2 + i) * (kQPad * 16u));
+    if (KB0 + N == 21) g.t_tail = ld2<RFX_STREAM_AUX>(src, q * 8u, 2u * foff + 20u * kQPad * 8u);
+  }
+}
+
+template <int MODE, int KB0, int N>
+__device__ __forceinline__ void stage_apply(cf (&R)[21], const Stage<KB0, N>& g, const GlStreams& st, unsigned foff,
+                                            unsigned q, bool active, float mom, unsigned long long seed,
+                                            unsigned long long rng_base, int k1, int ka) {
+  constexpr int NB = (KB0 + N == 21) ? N - 1 : N;
+  float Sm[N];
+  cf tp[N];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) Sm[i] = g.s4[i / 4][i % 4];
+  if (KB0 + N == 21) Sm[N - 1] = g.s_tail;
+  if (MODE == 2 || (MODE == 0 && st.have_init)) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) tp[i] = cf{g.t4[i / 2][2 * (i % 2)], g.t4[i / 2][2 * (i % 2) + 1]};
+    if (KB0 + N == 21) tp[N - 1] = cf{g.t_tail.x, g.t_tail.y};
+  } else if (MODE == 0) {
+    // rand_init=True (spectrogram_converter.py:72): U[0,1) real and imaginary parts per BIN, so a
+    // conjugate slot draws the same pair as its primary and conjugates it
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      bool cj;
+      const int bin = slot_bin(k1, ka, KB0 + i, &cj);
+      cf r = rand_unit_pair(seed, rng_base + bin);
+      tp[i] = cf{r.re, cj ? -r.im : r.im};
+    }
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) R[KB0 + i] = cf{Sm[i] * tp[i].re, Sm[i] * tp[i].im};
+  } else {
+#ifndef RFX_ABL_NOMEM
+    // tprev <- rebuilt (before R is overwritten by the next spectrum estimate)
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < NB / 2; ++i)
+        st4<RFX_STREAM_AUX>(v4f{R[KB0 + 2 * i].re, R[KB0 + 2 * i].im, R[KB0 + 2 * i + 1].re, R[KB0 + 2 * i + 1].im}, st.tprev,
+                    q * 16u, 2u * foff + (unsigned)(KB0 / 2 + i) * (kQPad * 16u));
+      if (KB0 + N == 21) st2<RFX_STREAM_AUX>(v2f{R[20].re, R[20].im}, st.tprev, q * 8u, 2u * foff + 20u * kQPad * 8u);
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const cf prev = (MODE == 1) ? cf{0.f, 0.f} : tp[i];
+      R[KB0 + i] = gl_update(R[KB0 + i], prev, (MODE == 1) ? 0.f : mom, Sm[i]);
+    }
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const ThreadId t = thread_id();
-  ThreadConst c;
-  load_thread_const(c, t, g.tw1, g.tw2, g.win);
+  const FrameCtx f = frame_ctx(smem, t, g.tw1, g.tw2);
 
   const int clip = blockIdx.x / g.nruns;
   const int run = blockIdx.x - clip * g.nruns;
@@ -34,102 +119,127 @@ __global__ void __launch_bounds__(kThreads) gl_iter_kernel(GlArgs g) {
   const int par = run & 1;
   const int nblk = g.T - 1;  // hop blocks kept by istft's centre trim
 
-  const float* __restrict__ in0 = g.audio_in[0] + (size_t)clip * g.Lpad;
-  const float* __restrict__ in1 = g.audio_in[1] + (size_t)clip * g.Lpad;
-  float* __restrict__ outA = g.audio_out[par] + (size_t)clip * g.Lpad;
-  float* __restrict__ outB = g.audio_out[par ^ 1] + (size_t)clip * g.Lpad;
+  const size_t clip_slots = (size_t)g.T * kFrameStride;
+  GlStreams st;
+  st.S = make_rsrc(g.S + clip * clip_slots, clip_slots * sizeof(float));
+  st.tprev = make_rsrc(g.tprev + clip * clip_slots, clip_slots * sizeof(cf));
+  st.have_init = g.angles0 != nullptr;
+  st.init = make_rsrc(st.have_init ? g.angles0 + clip * clip_slots : g.tprev, clip_slots * sizeof(cf));
+  const rsrc_t in0 = make_rsrc(g.audio_in[0] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+  const rsrc_t in1 = make_rsrc(g.audio_in[1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+  const rsrc_t outA = make_rsrc(g.audio_out[par] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+  const rsrc_t outB = make_rsrc(g.audio_out[par ^ 1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+  const rsrc_t scl = make_rsrc(g.out_scale, (size_t)g.L * 4);
+  const rsrc_t win = make_rsrc(g.win, kWin * 4);
+  const unsigned npr4 = (unsigned)t.npr * 4u;
 
   float acc[10];
 #pragma unroll
   for (int j = 0; j < 10; ++j) acc[j] = 0.f;
 
   auto emit = [&](int blk, float val) {
-    if (blk < 0 || blk >= nblk || !t.active) return;
-    const int p = blk * kHop + t.npr;
+    if (blk < 0 || blk >= nblk || !t.active) return;  // blk is wave-uniform
+    const unsigned boff = (unsigned)blk * (kHop * 4u);
     const bool full = (max(blk - 4, 0) >= t0) && (min(blk + 5, g.T - 1) <= t1);
-    outA[p] = val * g.out_scale[p];
-    if (full) outB[p] = 0.f;
+    st1(val * ld1(scl, npr4, boff), outA, npr4, boff);
+    if (full) st1(0.f, outB, npr4, boff);
   };
+  __syncthreads();  // tw2 table in LDS
 
+#ifdef RFX_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = wall_clock64();
+#define RFX_STAMP(i) do { unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define RFX_STAMP(i) ((void)0)
+#endif
   for (int fr = t0; fr <= t1; ++fr) {
-    const size_t fbase = ((size_t)clip * g.T + fr) * kFrameStride;
-    const int q = t.npr;
+    const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
+    const unsigned q = threadIdx.x;  // padded owner index of the slot streams
+    const unsigned long long rng_base = ((unsigned long long)clip * g.T + fr) * kBins;
 
-    // ---- issue the streaming loads of this frame first: |S| (4 kb per 16 B) and tprev (2 kb per 16 B)
-    float Sm[21];
-    {
-      const v4f* s4 = reinterpret_cast<const v4f*>(g.S + fbase);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        v4f v = __builtin_nontemporal_load(s4 + i * kHop + q);
-        Sm[4 * i] = v.x; Sm[4 * i + 1] = v.y; Sm[4 * i + 2] = v.z; Sm[4 * i + 3] = v.w;
-      }
-      Sm[20] = __builtin_nontemporal_load(g.S + fbase + 20 * kHop + q);
-    }
-    cf tp[21];
-    if (MODE != 1) {
-      const cf* src = (MODE == 0) ? g.angles0 : g.tprev;
-      if (MODE == 2 || src != nullptr) {
-        const v4f* t4 = reinterpret_cast<const v4f*>(src + fbase);
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-          v4f v = __builtin_nontemporal_load(t4 + i * kHop + q);
-          tp[2 * i] = cf{v.x, v.y};
-          tp[2 * i + 1] = cf{v.z, v.w};
-        }
-        const v2f* t2 = reinterpret_cast<const v2f*>(src + fbase);
-        v2f w = __builtin_nontemporal_load(t2 + 20 * kHop + q);
-        tp[20] = cf{w.x, w.y};
-      } else {
-        // rand_init=True (spectrogram_converter.py:72): U[0,1) real and imaginary parts per BIN, so
-        // a conjugate slot draws the same pair as its primary and conjugates it
-#pragma unroll
-        for (int kb = 0; kb < 21; ++kb) {
-          bool cj;
-          const int bin = slot_bin(t.k1, t.idx, kb, &cj);
-          cf r = rand_unit_pair(g.seed, ((unsigned long long)clip * g.T + fr) * kBins + bin);
-          tp[kb] = cf{r.re, cj ? -r.im : r.im};
-        }
-      }
-    }
-
-    cf Z[21];
-    if (MODE == 0) {
-#pragma unroll
-      for (int kb = 0; kb < 21; ++kb) Z[kb] = cf{Sm[kb] * tp[kb].re, Sm[kb] * tp[kb].im};
-    } else {
+    cf R[21];
+#ifndef RFX_SPLIT_A
+#define RFX_SPLIT_A 8
+#endif
+#ifndef RFX_SPLIT_B
+#define RFX_SPLIT_B 8
+#endif
+#ifndef RFX_EARLY_ISSUE
+#define RFX_EARLY_ISSUE 0  // 1: put stage A in flight under P2/P3 (needs a spill-free build to pay off)
+#endif
+#ifndef RFX_STREAM_AUX
+#define RFX_STREAM_AUX 2
+#endif
+    Stage<0, RFX_SPLIT_A> sa;
+    Stage<RFX_SPLIT_A, RFX_SPLIT_B> sb;
+    Stage<RFX_SPLIT_A + RFX_SPLIT_B, 21 - RFX_SPLIT_A - RFX_SPLIT_B> sc;
+    auto issue_a = [&] {
+#if !defined(RFX_ABL_NOMEM) && RFX_EARLY_ISSUE
+      stage_issue<MODE>(sa, st, foff, q);
+#endif
+    };
+    if (MODE != 0) {
       // ---- analysis: reflect-padded, Hann-windowed frame centred on sample 441*fr
       float u[10];
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
-        const int p = reflect_index((fr + j - kHalfHops) * kHop + t.npr, g.L);
-        u[j] = (in0[p] + in1[p]) * c.win[j];
+        const unsigned p4 = (unsigned)reflect_index((fr + j - kHalfHops) * kHop + t.npr, g.L) * 4u;
+        u[j] = (ld1(in0, p4, 0) + ld1(in1, p4, 0)) * ld1(win, npr4, (unsigned)j * (kHop * 4u));
       }
-      cf R[21];
-      frame_forward(u, R, cube, t, c);
-
-      // ---- momentum phase update; tprev <- rebuilt
+#ifdef RFX_ABL_NOFFT
+      issue_a();
 #pragma unroll
-      for (int kb = 0; kb < 21; ++kb) {
-        const cf prev = (MODE == 1) ? cf{0.f, 0.f} : tp[kb];
-        Z[kb] = gl_update(R[kb], prev, (MODE == 1) ? 0.f : g.mom, Sm[kb]);
-      }
-      if (t.active) {
-        v4f* t4 = reinterpret_cast<v4f*>(g.tprev + fbase);
-#pragma unroll
-        for (int i = 0; i < 10; ++i)
-          __builtin_nontemporal_store(v4f{R[2 * i].re, R[2 * i].im, R[2 * i + 1].re, R[2 * i + 1].im},
-                                      t4 + i * kHop + q);
-        v2f* t2 = reinterpret_cast<v2f*>(g.tprev + fbase);
-        __builtin_nontemporal_store(v2f{R[20].re, R[20].im}, t2 + 20 * kHop + q);
-      }
+      for (int kb = 0; kb < 21; ++kb) R[kb] = cf{u[kb % 10], u[(kb + 3) % 10]};
+#else
+      frame_forward(u, R, f, t, [&] { RFX_STAMP(1); issue_a(); }, [&] { RFX_STAMP(0); });
+      RFX_STAMP(2);
+#endif
+    } else {
+      issue_a();
     }
+    // ---- momentum phase update; R becomes the next spectrum estimate
+#ifdef RFX_ABL_NOMEM
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { sa.s4[i] = v4f{1.f, 2.f, 3.f, 4.f}; sb.s4[i] = v4f{1.f, 2.f, 3.f, 4.f}; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sa.t4[i] = v4f{.1f, .2f, .3f, .4f}; sb.t4[i] = v4f{.1f, .2f, .3f, .4f}; }
+    sc.s4[0] = v4f{1.f, 2.f, 3.f, 4.f}; sc.t4[0] = sc.t4[1] = v4f{.1f, .2f, .3f, .4f}; sc.s_tail = 2.f; sc.t_tail = v2f{.3f, .1f};
+#elif RFX_EARLY_ISSUE
+    stage_issue<MODE>(sb, st, foff, q);
+    RFX_SCHED_FENCE();
+#else
+    stage_issue<MODE>(sa, st, foff, q);
+#endif
+    stage_apply<MODE>(R, sa, st, foff, q, t.active, g.mom, g.seed, rng_base, t.k1, t.idx);
+#ifndef RFX_ABL_NOMEM
+    RFX_SCHED_FENCE();
+#if RFX_EARLY_ISSUE
+    stage_issue<MODE>(sc, st, foff, q);
+#else
+    stage_issue<MODE>(sb, st, foff, q);
+#endif
+    RFX_SCHED_FENCE();
+#endif
+    stage_apply<MODE>(R, sb, st, foff, q, t.active, g.mom, g.seed, rng_base, t.k1, t.idx);
+    RFX_SCHED_FENCE();
+#if !defined(RFX_ABL_NOMEM) && !RFX_EARLY_ISSUE
+    stage_issue<MODE>(sc, st, foff, q);
+#endif
+    stage_apply<MODE>(R, sc, st, foff, q, t.active, g.mom, g.seed, rng_base, t.k1, t.idx);
+    RFX_SCHED_FENCE();
+    RFX_STAMP(3);
 
     // ---- synthesis: inverse transform, synthesis window, overlap-add into the sliding window
     float y[10];
-    frame_inverse(Z, y, cube, t, c);
+#ifdef RFX_ABL_NOFFT
 #pragma unroll
-    for (int j = 0; j < 10; ++j) acc[j] = fmaf(y[j], c.win[j], acc[j]);
+    for (int j = 0; j < 10; ++j) y[j] = R[j].re + R[j + 10].im + R[20].re;
+#else
+    frame_inverse(R, y, f, t, [&] { RFX_STAMP(4); }, [&] { RFX_STAMP(5); });
+#endif
+#pragma unroll
+    for (int j = 0; j < 10; ++j) acc[j] = fmaf(y[j], ld1(win, npr4, (unsigned)j * (kHop * 4u)), acc[j]);
     emit(fr - kHalfHops, acc[0]);
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = acc[j + 1];
@@ -137,7 +247,14 @@ __global__ void __launch_bounds__(kThreads) gl_iter_kernel(GlArgs g) {
     // MODE 0 has no analysis half: its next P3' store would overwrite rows whose columns other
     // waves are still gathering in P1'
     if (MODE == 0) __syncthreads();
+    RFX_STAMP(6);
   }
+#ifdef RFX_TIMING
+  if (g.timing && (threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    for (int i = 0; i < 8; ++i) g.timing[((size_t)blockIdx.x * 7 + w) * 8 + i] = tacc[i];
+  }
+#endif
   // ---- flush the right halo of the run
 #pragma unroll
   for (int j = 0; j < 9; ++j) emit(t1 - 4 + j, acc[j]);
@@ -154,7 +271,7 @@ __global__ void gl_combine_kernel(const float* a0, const float* a1, float* out, 
 }
 
 hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t stream) {
-  const size_t lds = sizeof(cf) * kSlots;
+  const size_t lds = kFrameLdsBytes;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)gl_iter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -168,6 +285,19 @@ hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t st
     default: hipLaunchKernelGGL(gl_iter_kernel<2>, dim3(nblocks), dim3(kThreads), lds, stream, g); break;
   }
   return hipGetLastError();
+}
+
+int gl_blocks_per_cu() {
+  static int cached = 0;
+  if (cached) return cached;
+  if (const char* e = getenv("RFX_GL_WGS_PER_CU")) {
+    cached = atoi(e) > 0 ? atoi(e) : 1;
+    return cached;
+  }
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gl_iter_kernel<2>, kThreads, kFrameLdsBytes) != hipSuccess || n < 1) n = 1;
+  cached = n;
+  return cached;
 }
 
 hipError_t launch_gl_combine(const float* a0, const float* a1, float* out, int B, int L, int Lpad, hipStream_t stream) {

@@ -19,9 +19,11 @@ struct GlArgs {
   int B, T, L, Lpad, nruns;
   float mom;                  // momentum / (1 + momentum)
   unsigned long long seed;
+  unsigned long long* timing;  // optional [nblocks][8] phase timers (RFX_TIMING builds only)
 };
 
 hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t stream);
+int gl_blocks_per_cu();  // resident Griffin-Lim workgroups per CU (occupancy query)
 hipError_t launch_gl_combine(const float* a0, const float* a1, float* out, int B, int L, int Lpad, hipStream_t stream);
 
 // layout conversion between the reference's (B, n_stft, T) tensors and slot-major frames

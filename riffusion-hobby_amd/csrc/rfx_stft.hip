@@ -6,38 +6,24 @@
 
 namespace rfx {
 
-// ---- inverse of slot_pos_f / slot_pos_c: position inside a frame -> (q, kb)
-__device__ __forceinline__ void pos_f_to_slot(int p, int& q, int& kb) {
-  if (p < 20 * kHop) {
-    const int g = p / (4 * kHop), rem = p - g * 4 * kHop;
-    q = rem >> 2;
-    kb = 4 * g + (rem & 3);
-  } else {
-    q = p - 20 * kHop;
-    kb = 20;
-  }
-}
-__device__ __forceinline__ void pos_c_to_slot(int p, int& q, int& kb) {
-  if (p < 20 * kHop) {
-    const int g = p / (2 * kHop), rem = p - g * 2 * kHop;
-    q = rem >> 1;
-    kb = 2 * g + (rem & 1);
-  } else {
-    q = p - 20 * kHop;
-    kb = 20;
-  }
-}
-
 // one thread per slot position, 16 consecutive frames: reads 64 contiguous bytes of a bin row and
 // writes position-contiguous (coalesced) floats into 16 frames
 template <bool COMPLEX>
 __global__ void __launch_bounds__(256) pack_kernel(const void* __restrict__ src_, void* __restrict__ dst_, int T) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= kSlots) return;
+  if (p >= kFrameStride) return;
   const int tchunk = blockIdx.y * 16;
   const int clip = blockIdx.z;
   int q, kb;
-  if (COMPLEX) pos_c_to_slot(p, q, kb); else pos_f_to_slot(p, q, kb);
+  const bool real_slot = COMPLEX ? pos_c_to_slot(p, q, kb) : pos_f_to_slot(p, q, kb);
+  if (!real_slot) {  // padding lane: keep it zero
+    const int ntp = min(16, T - tchunk);
+    for (int i = 0; i < ntp; ++i) {
+      const size_t o = ((size_t)clip * T + tchunk + i) * kFrameStride + p;
+      if (COMPLEX) reinterpret_cast<cf*>(dst_)[o] = cf{0.f, 0.f}; else reinterpret_cast<float*>(dst_)[o] = 0.f;
+    }
+    return;
+  }
   bool cj;
   const int bin = slot_bin(q / 21, q % 21, kb, &cj);
   const int nt = min(16, T - tchunk);
@@ -77,12 +63,12 @@ __global__ void __launch_bounds__(256) unpack_complex_kernel(const cf* __restric
 }
 
 hipError_t launch_pack_mag(const float* lin_bft, float* S_slots, int B, int T, hipStream_t stream) {
-  dim3 grid((kSlots + 255) / 256, (T + 15) / 16, B);
+  dim3 grid((kFrameStride + 255) / 256, (T + 15) / 16, B);
   hipLaunchKernelGGL(pack_kernel<false>, grid, dim3(256), 0, stream, (const void*)lin_bft, (void*)S_slots, T);
   return hipGetLastError();
 }
 hipError_t launch_pack_angles(const cf* ang_bft, cf* slots, int B, int T, hipStream_t stream) {
-  dim3 grid((kSlots + 255) / 256, (T + 15) / 16, B);
+  dim3 grid((kFrameStride + 255) / 256, (T + 15) / 16, B);
   hipLaunchKernelGGL(pack_kernel<true>, grid, dim3(256), 0, stream, (const void*)ang_bft, (void*)slots, T);
   return hipGetLastError();
 }
@@ -95,10 +81,10 @@ hipError_t launch_unpack_complex(const cf* slots, cf* out_bft, int B, int T, hip
 // ---- forward STFT: frame t of clip b is centred on sample 441*t of the reflect-padded waveform
 __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cf* cube = reinterpret_cast<cf*>(smem);
   const ThreadId t = thread_id();
-  ThreadConst c;
-  load_thread_const(c, t, a.tw1, a.tw2, a.win);
+  const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
+  const float* __restrict__ winp = a.win + t.npr;
+  __syncthreads();
 
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   const int clip = blockIdx.x / chunks;
@@ -111,34 +97,38 @@ __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
       const int p = reflect_index((fr + j - kHalfHops) * kHop + t.npr, a.Lw);
-      u[j] = x[p] * c.win[j];
+      u[j] = x[p] * winp[j * kHop];
     }
     cf R[21];
-    frame_forward(u, R, cube, t, c);
+    frame_forward(u, R, f, t, [] {});
     const size_t fbase = ((size_t)clip * a.T + fr) * kFrameStride;
-    const int q = t.npr;
-    if (t.active && a.mag) {
+    const int q = threadIdx.x;  // padded owner index
+    if (a.mag) {  // the padding lane of each wave stores zeros (keeps the mel GEMM free of garbage)
       float m[21];
 #pragma unroll
-      for (int kb = 0; kb < 21; ++kb) m[kb] = sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
+      for (int kb = 0; kb < 21; ++kb) m[kb] = t.active ? sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im)) : 0.f;
       float4* d4 = reinterpret_cast<float4*>(a.mag + fbase);
 #pragma unroll
-      for (int i = 0; i < 5; ++i) d4[i * kHop + q] = float4{m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]};
-      a.mag[fbase + 20 * kHop + q] = m[20];
+      for (int i = 0; i < 5; ++i) d4[i * kQPad + q] = float4{m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]};
+      a.mag[fbase + 20 * kQPad + q] = m[20];
     }
-    if (t.active && a.spec) {
+    if (a.spec) {
+      if (!t.active) {
+#pragma unroll
+        for (int kb = 0; kb < 21; ++kb) R[kb] = cf{0.f, 0.f};
+      }
       float4* d4 = reinterpret_cast<float4*>(a.spec + fbase);
 #pragma unroll
       for (int i = 0; i < 10; ++i)
-        d4[i * kHop + q] = float4{R[2 * i].re, R[2 * i].im, R[2 * i + 1].re, R[2 * i + 1].im};
-      a.spec[fbase + 20 * kHop + q] = R[20];
+        d4[i * kQPad + q] = float4{R[2 * i].re, R[2 * i].im, R[2 * i + 1].re, R[2 * i + 1].im};
+      a.spec[fbase + 20 * kQPad + q] = R[20];
     }
     __syncthreads();  // the next frame's P1 overwrites rows other waves may still be reading in P3
   }
 }
 
 hipError_t launch_stft(const StftArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(cf) * kSlots;
+  const size_t lds = kFrameLdsBytes;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -17,7 +17,7 @@ import typing as T
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "librfx.so")
+_LIB_PATH = os.environ.get("RFX_LIB_PATH") or os.path.join(os.path.dirname(_PKG_DIR), "librfx.so")
 
 _lib: T.Optional[ctypes.CDLL] = None
 _lib_lock = threading.Lock()

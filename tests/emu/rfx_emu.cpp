@@ -38,13 +38,13 @@ void emu_forward(const float* seg, float* out_slots) {
     cf v[21], t1[21];
     for (int k = 0; k < 21; ++k) t1[k] = tw1[n * 21 + k];
     p1_forward(u, v);
-    p1_store(v, t1, cube.data(), n);
+    p1_store(v, [&](int k) { return t1[k]; }, cube.data(), n);
   }
   for (int k1 = 0; k1 < 21; ++k1)  // P2
     for (int b = 0; b < 21; ++b) {
       cf t2[21];
       for (int i = 0; i < 21; ++i) t2[i] = tw2[b * 21 + i];
-      p2_forward(cube.data(), t2, k1, b);
+      p2_forward(cube.data(), [&](int k) { return t2[k]; }, k1, b);
     }
   for (int k1 = 0; k1 < 21; ++k1)  // P3
     for (int ka = 0; ka < 21; ++ka) {
@@ -67,14 +67,14 @@ void emu_inverse(const float* in_slots, float* y) {
       for (int kb = 0; kb < 21; ++kb)
         Z[kb] = cf{in_slots[((k1 * 21 + ka) * 21 + kb) * 2], in_slots[((k1 * 21 + ka) * 21 + kb) * 2 + 1]};
       for (int i = 0; i < 21; ++i) t2[i] = tw2[ka * 21 + i];
-      p3_inverse(cube.data(), Z, t2, k1, ka);
+      p3_inverse(cube.data(), Z, [&](int k) { return t2[k]; }, k1, ka);
     }
   for (int k1 = 0; k1 < 21; ++k1)
     for (int b = 0; b < 21; ++b) p2_inverse(cube.data(), k1, b);
   for (int n = 0; n < 441; ++n) {
     cf V[21], t1[21];
     for (int k = 0; k < 21; ++k) t1[k] = tw1[n * 21 + k];
-    p1_load(cube.data(), t1, V, n);
+    p1_load(cube.data(), [&](int k) { return t1[k]; }, V, n);
     float yy[10];
     p1_inverse(V, yy);
     for (int j = 0; j < 10; ++j) y[441 * j + n] = yy[j];
