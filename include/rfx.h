@@ -86,6 +86,45 @@ int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d
                    int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
                    void* stream);
 
+/* slots (float32) -> (B, n_stft, T) float32 */
+int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int T, float* d_bft, void* stream);
+
+/* ---- forward: mel_amplitudes_from_waveform, spectrogram_converter.py:165-185
+ * Spectrogram(power=None) -> torch.abs -> MelScale (matmul with the filterbank, on the fp32 MFMA).
+ * d_wave (B, Lw) float32 -> d_mel_out (B, n_mels, T) float32, T = 1 + Lw / hop. */
+size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw);
+int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ---- inverse: torchaudio.transforms.InverseMelScale (SGD, max_iter = params.max_mel_iters,
+ * tolerance_loss 1e-5, tolerance_change 1e-8, lr 0.1, momentum 0.9), spectrogram_converter.py:87-99,
+ * called at :201.  d_mel (B, n_mels, T); the B rows are grouped into clips of `channels_per_clip`
+ * consecutive rows, each clip being one call of the reference (its loss mean couples the clip's
+ * channels and frames).  d_spec0: optional injected start (B, T, n_stft) float32 in the reference's
+ * own layout, NULL = U[0,1) from `seed`.  Output: linear magnitudes in slot layout, ready for
+ * rfx_griffinlim. */
+size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T);
+int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
+                    uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- image codec: riffusion/util/image_util.py -----------------------------------------------
+ * decode = spectrogram_from_image (:81-108): d_img (N, H, W, 3) uint8 RGB -> (N*C, H, W) float32,
+ *   C = 2 (G,B planes) when stereo else 1 (R plane); d_lut256[p] is the float32 value numpy's chain
+ *   255-p, /255, **(1/power), *max_value gives for pixel value p (built on the host WITH numpy).
+ * encode = image_from_spectrogram (:27-54): d_mel (N*C, M, T) float32 -> d_img_out (N, M, T, 3) uint8;
+ *   the per-clip maximum is written to d_clip_max (N floats; it is the EXIF MAX_VALUE of
+ *   spectrogram_image_converter.py:59); d_thresholds255[v] = smallest float32 ratio x/max whose
+ *   numpy result is <= v (descending, built on the host WITH numpy). */
+int rfx_image_decode_u8(const uint8_t* d_img, int N, int H, int W, int stereo, const float* d_lut256, float* d_mel_out,
+                        void* stream);
+int rfx_image_encode_u8(const float* d_mel, int N, int M, int T, int stereo, const float* d_thresholds255, float* d_clip_max,
+                        uint8_t* d_img_out, void* stream);
+
+/* ---- PCM tail: riffusion/util/audio_util.py:22-28.  d_wave (N*C, L) float32 -> d_pcm_out (N, L, C)
+ * int16: joint peak normalisation over a clip's channels (when normalize != 0), truncation toward
+ * zero.  d_clip_peak (N floats) receives max|x| per clip. */
+int rfx_pcm16(const float* d_wave, int N, int C, int L, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

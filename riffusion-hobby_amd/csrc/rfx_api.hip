@@ -40,6 +40,14 @@ struct rfx_plan {
   float* d_win = nullptr;   // [4410]
   float* d_melfb_slots = nullptr;  // [kFrameStride][n_mels]: filterbank rows permuted to slot order
   float* d_melfb = nullptr;        // [n_stft][n_mels] as given
+  int* d_kblocks = nullptr;        // non-zero 32-position K blocks of d_melfb_slots
+  int n_kblocks = 0;
+  // banded view of the filterbank for InverseMelScale (valid when imel_ok)
+  bool imel_ok = false;
+  std::string imel_why;
+  ImelTables imel{};
+  void* d_imel_blob = nullptr;
+  int* d_bin_pos = nullptr;        // [n_stft] primary slot position, [n_stft] duplicate (-1)
 };
 
 namespace rfx {
@@ -123,6 +131,96 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
         }
     RFX_HIP(hipMalloc(&pl->d_melfb_slots, fbs.size() * sizeof(float)));
     RFX_HIP(hipMemcpy(pl->d_melfb_slots, fbs.data(), fbs.size() * sizeof(float), hipMemcpyHostToDevice));
+    // K blocks (32 slot positions) with at least one non-zero filterbank row
+    std::vector<int> kb;
+    for (int blk = 0; blk < kFrameStride / 32; ++blk) {
+      bool nz = false;
+      for (int r = blk * 32; r < blk * 32 + 32 && !nz; ++r)
+        for (int m = 0; m < M; ++m)
+          if (fbs[(size_t)r * M + m] != 0.f) { nz = true; break; }
+      if (nz) kb.push_back(blk);
+    }
+    pl->n_kblocks = (int)kb.size();
+    RFX_HIP(hipMalloc(&pl->d_kblocks, (kb.size() + 1) * sizeof(int)));
+    RFX_HIP(hipMemcpy(pl->d_kblocks, kb.data(), kb.size() * sizeof(int), hipMemcpyHostToDevice));
+
+    // ---- banded tables for InverseMelScale: every bin feeds at most two ADJACENT mel filters and
+    // every filter's support is one contiguous run of bins (true for torchaudio's triangular banks)
+    std::vector<int> bin_m0(kBins, -1), band_lo(M, 0), band_hi(M, 0), csr_ptr(M + 1, 0);
+    std::vector<float> bin_w0(kBins, 0.f), bin_w1(kBins, 0.f), csr_w;
+    bool ok = true;
+    std::string why;
+    int f_lo = kBins, f_hi = 0;
+    for (int f = 0; f < kBins && ok; ++f) {
+      int first = -1, cnt = 0, last = -1;
+      for (int m = 0; m < M; ++m)
+        if (h_melfb[(size_t)f * M + m] != 0.f) { if (first < 0) first = m; last = m; ++cnt; }
+      if (cnt == 0) continue;
+      if (cnt > 2 || last - first != cnt - 1) { ok = false; why = "a linear bin feeds more than two adjacent mel filters"; break; }
+      bin_m0[f] = first;
+      bin_w0[f] = h_melfb[(size_t)f * M + first];
+      bin_w1[f] = cnt == 2 ? h_melfb[(size_t)f * M + first + 1] : 0.f;
+      f_lo = f < f_lo ? f : f_lo;
+      f_hi = f + 1;
+    }
+    for (int m = 0; m < M && ok; ++m) {
+      int lo = -1, hi = -1;
+      for (int f = 0; f < kBins; ++f)
+        if (h_melfb[(size_t)f * M + m] != 0.f) { if (lo < 0) lo = f; hi = f + 1; }
+      if (lo < 0) { lo = hi = (f_lo < kBins ? f_lo : 0); }
+      for (int f = lo; f < hi; ++f)
+        if (h_melfb[(size_t)f * M + m] == 0.f) { ok = false; why = "a mel filter's support is not contiguous"; break; }
+      band_lo[m] = lo;
+      band_hi[m] = hi;
+      csr_ptr[m] = (int)csr_w.size();
+      for (int f = lo; f < hi; ++f) csr_w.push_back(h_melfb[(size_t)f * M + m]);
+    }
+    csr_ptr[M] = (int)csr_w.size();
+    if (ok && (f_hi <= f_lo)) { ok = false; why = "empty filterbank"; }
+    if (ok && (f_hi - f_lo > 36 * 256)) { ok = false; why = "more than 9216 active bins"; }
+    if (ok && M > 1024) { ok = false; why = "more than 1024 mel filters"; }
+    std::vector<int> bin_pos(kBins, -1), bin_pos2(kBins, -1);
+    for (int k1 = 0; k1 < 21; ++k1)
+      for (int ka = 0; ka < 21; ++ka)
+        for (int kbq = 0; kbq < 21; ++kbq) {
+          bool cj;
+          const int bin = slot_bin(k1, ka, kbq, &cj);
+          const int pos = slot_pos_f(k1 * 21 + ka, kbq);
+          if (bin_pos[bin] < 0) bin_pos[bin] = pos; else bin_pos2[bin] = pos;
+        }
+    pl->imel_ok = ok;
+    pl->imel_why = why;
+    if (ok) {
+      // one device blob: csr_w | csr_ptr | band_lo | bin_m0 | bin_w0 | bin_w1 | bin_pos | bin_pos2
+      const size_t nnz = csr_w.size();
+      size_t off = 0;
+      auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+      const size_t o_w = take(nnz * 4), o_ptr = take((M + 1) * 4), o_lo = take(M * 4), o_m0 = take(kBins * 4),
+                   o_w0 = take(kBins * 4), o_w1 = take(kBins * 4), o_p = take(kBins * 4), o_p2 = take(kBins * 4);
+      std::vector<char> blob(off);
+      memcpy(&blob[o_w], csr_w.data(), nnz * 4);
+      memcpy(&blob[o_ptr], csr_ptr.data(), (M + 1) * 4);
+      memcpy(&blob[o_lo], band_lo.data(), M * 4);
+      memcpy(&blob[o_m0], bin_m0.data(), kBins * 4);
+      memcpy(&blob[o_w0], bin_w0.data(), kBins * 4);
+      memcpy(&blob[o_w1], bin_w1.data(), kBins * 4);
+      memcpy(&blob[o_p], bin_pos.data(), kBins * 4);
+      memcpy(&blob[o_p2], bin_pos2.data(), kBins * 4);
+      RFX_HIP(hipMalloc(&pl->d_imel_blob, off));
+      RFX_HIP(hipMemcpy(pl->d_imel_blob, blob.data(), off, hipMemcpyHostToDevice));
+      char* d = (char*)pl->d_imel_blob;
+      pl->imel.csr_w = (const float*)(d + o_w);
+      pl->imel.csr_ptr = (const int*)(d + o_ptr);
+      pl->imel.band_lo = (const int*)(d + o_lo);
+      pl->imel.bin_m0 = (const int*)(d + o_m0);
+      pl->imel.bin_w0 = (const float*)(d + o_w0);
+      pl->imel.bin_w1 = (const float*)(d + o_w1);
+      pl->imel.bin_pos = (const int*)(d + o_p);
+      pl->imel.bin_pos2 = (const int*)(d + o_p2);
+      pl->imel.f_lo = f_lo;
+      pl->imel.f_hi = f_hi;
+      pl->imel.nnz = (int)nnz;
+    }
   }
   *out_plan = pl;
   return RFX_OK;
@@ -135,6 +233,8 @@ int rfx_plan_destroy(rfx_plan* plan) {
   hipFree(plan->d_win);
   hipFree(plan->d_melfb);
   hipFree(plan->d_melfb_slots);
+  hipFree(plan->d_kblocks);
+  hipFree(plan->d_imel_blob);
   delete plan;
   return RFX_OK;
 }
@@ -260,6 +360,109 @@ int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d
     RFX_HIP(launch_gl_iter(it == 1 ? 1 : 2, g, nblocks, stream));
   }
   RFX_HIP(launch_gl_combine(bufs[2 * cur], bufs[2 * cur + 1], d_wave_out, B, L, Lpad, stream));
+  return RFX_OK;
+}
+
+int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int T, float* d_bft, void* stream) {
+  if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_unpack_magnitudes: bad argument");
+  RFX_HIP(launch_unpack_mag(d_slots, d_bft, B, T, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw) {
+  if (!plan || B <= 0 || Lw <= kNfft / 2) return 0;
+  const size_t T = 1 + Lw / kHop;
+  return align_up((size_t)B * T * kFrameStride * sizeof(float), 256);
+}
+
+int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!plan || !d_wave || !d_mel_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: null argument");
+  if (!plan->d_melfb_slots) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: plan was created without a mel filterbank");
+  if (workspace_bytes < rfx_mel_workspace_bytes(plan, B, Lw) || Lw <= kNfft / 2)
+    return fail(Lw <= kNfft / 2 ? RFX_ERR_INVALID : RFX_ERR_WORKSPACE, "rfx_mel_from_waveform: input too short or workspace too small");
+  float* mag = (float*)d_workspace;
+  int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
+  if (rc) return rc;
+  MelArgs a;
+  a.mag = mag;
+  a.fbs = plan->d_melfb_slots;
+  a.kblocks = plan->d_kblocks;
+  a.n_kblocks = plan->n_kblocks;
+  a.out = d_mel_out;
+  a.M = plan->p.n_mels;
+  a.T = 1 + Lw / kHop;
+  a.N = B * a.T;
+  RFX_HIP(launch_mel_gemm(a, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T) {
+  if (!plan || B <= 0 || T <= 0) return 0;
+  return align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256) + align_up((size_t)(B + 1) * sizeof(int), 256);
+}
+
+int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
+                    uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_) {
+  if (!plan || !d_mel || !d_mag_slots || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: null argument");
+  if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: plan was created without a mel filterbank");
+  if (!plan->imel_ok) return fail(RFX_ERR_UNSUPPORTED, "rfx_inverse_mel: filterbank is not banded: " + plan->imel_why);
+  if (B <= 0 || T <= 0 || channels_per_clip <= 0 || B % channels_per_clip)
+    return fail(RFX_ERR_INVALID, "rfx_inverse_mel: batch must be a multiple of channels_per_clip");
+  if (workspace_bytes < rfx_inverse_mel_workspace_bytes(plan, B, T)) return fail(RFX_ERR_WORKSPACE, "rfx_inverse_mel: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nclips = B / channels_per_clip;
+  char* ws = (char*)d_workspace;
+  float* hist = (float*)ws;
+  int* it_stop = (int*)(ws + align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256));
+  int* any_early = it_stop + nclips;
+  RFX_HIP(hipMemsetAsync(any_early, 0, sizeof(int), stream));
+  ImelArgs a;
+  a.tb = plan->imel;
+  a.mel = d_mel;
+  a.spec0 = d_spec0;
+  a.out_slots = d_mag_slots;
+  a.loss_hist = hist;
+  a.it_limit = nullptr;
+  a.B = B;
+  a.M = plan->p.n_mels;
+  a.T = T;
+  a.C = channels_per_clip;
+  a.max_iter = plan->p.max_mel_iters;
+  a.lr = 0.1f;        // sgdargs=None -> {"lr": 0.1, "momentum": 0.9} (torchaudio 0.13 InverseMelScale)
+  a.momentum = 0.9f;
+  a.seed = seed;
+  if (a.max_iter <= 0) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: max_mel_iters must be positive");
+  RFX_HIP(launch_imel(a, stream));
+  // reproduce the reference's early exit (tolerance_loss 1e-5, tolerance_change 1e-8,
+  // spectrogram_converter.py:94-95): scan the clip losses, then re-run stopped clips for it_stop steps
+  RFX_HIP(launch_imel_scan(hist, it_stop, any_early, nclips, channels_per_clip, T, a.max_iter, 1e-5f, 1e-8f, stream));
+  a.it_limit = it_stop;
+  RFX_HIP(launch_imel(a, stream));
+  return RFX_OK;
+}
+
+int rfx_image_decode_u8(const uint8_t* d_img, int N, int H, int W, int stereo, const float* d_lut256, float* d_mel_out,
+                        void* stream) {
+  if (!d_img || !d_lut256 || !d_mel_out || N <= 0 || H <= 0 || W <= 0) return fail(RFX_ERR_INVALID, "rfx_image_decode_u8: bad argument");
+  RFX_HIP(launch_image_decode(d_img, d_lut256, d_mel_out, N, H, W, stereo ? 2 : 1, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+int rfx_image_encode_u8(const float* d_mel, int N, int M, int T, int stereo, const float* d_thresholds255, float* d_clip_max,
+                        uint8_t* d_img_out, void* stream) {
+  if (!d_mel || !d_thresholds255 || !d_clip_max || !d_img_out || N <= 0 || M <= 0 || T <= 0)
+    return fail(RFX_ERR_INVALID, "rfx_image_encode_u8: bad argument");
+  const int C = stereo ? 2 : 1;
+  RFX_HIP(launch_clip_max(d_mel, d_clip_max, N, (size_t)C * M * T, false, (hipStream_t)stream));
+  RFX_HIP(launch_image_encode(d_mel, d_clip_max, d_thresholds255, d_img_out, N, M, T, C, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+int rfx_pcm16(const float* d_wave, int N, int C, int L, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* stream) {
+  if (!d_wave || !d_clip_peak || !d_pcm_out || N <= 0 || C <= 0 || L <= 0) return fail(RFX_ERR_INVALID, "rfx_pcm16: bad argument");
+  if (normalize) RFX_HIP(launch_clip_max(d_wave, d_clip_peak, N, (size_t)C * L, true, (hipStream_t)stream));
+  RFX_HIP(launch_pcm16(d_wave, d_clip_peak, d_pcm_out, N, L, C, normalize, (hipStream_t)stream));
   return RFX_OK;
 }
 

@@ -1,0 +1,151 @@
+// rfx_codec.hip - the two ends of the hot path on the device:
+//   * uint8 spectrogram image <-> float mel amplitudes  (riffusion/util/image_util.py:13-110)
+//   * float waveform -> peak-normalised int16 PCM       (riffusion/util/audio_util.py:22-28)
+// All three are byte / integer exact by construction: the only transcendental in the chain
+// (numpy's float32 power curve) is never evaluated on the device - the decoder gathers from a
+// 256-entry table and the encoder searches 255 thresholds, both generated on the host by running
+// numpy's own float32 chain over the finitely many cases.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rfx_kernels.h"
+
+namespace rfx {
+
+// ---- decode: image_util.spectrogram_from_image (:81-108).  img (N, H, W, 3) uint8 RGB ->
+// out (N*C, H, W) float32, C = 2 picks G,B (:89-91), C = 1 picks R (:92-93); rows flipped (:85);
+// lut[p] = float32(((255 - p) / 255) ** (1/power) * max_value) as numpy computes it (:96-108).
+__global__ void __launch_bounds__(256) image_decode_kernel(const uint8_t* __restrict__ img, const float* __restrict__ lut,
+                                                          float* __restrict__ out, int H, int W, int C, size_t total) {
+  __shared__ float lut_s[256];
+  lut_s[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int w = (int)(i % W);
+    const size_t r = i / W;
+    const int h = (int)(r % H);
+    const size_t nc = r / H;
+    const int c = (int)(nc % C);
+    const size_t n = nc / C;
+    const int ch = (C == 2) ? 1 + c : 0;
+    out[i] = lut_s[img[((n * H + (H - 1 - h)) * W + w) * 3 + ch]];
+  }
+}
+
+// ---- per-clip maximum (of x or |x|) over `count` contiguous floats; one workgroup per clip.
+template <bool ABS>
+__global__ void __launch_bounds__(1024) clip_max_kernel(const float* __restrict__ x, float* __restrict__ out, size_t count) {
+  __shared__ float red[16];
+  const float* p = x + (size_t)blockIdx.x * count;
+  float m = -__builtin_inff();
+  bool nan = false;
+  for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
+    float v = p[i];
+    if (ABS) v = fabsf(v);
+    nan |= (v != v);
+    m = fmaxf(m, v);
+  }
+  if (nan) m = __builtin_nanf("");  // np.max propagates NaN
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float other = __shfl_xor(m, o);
+    m = (m != m || other != other) ? __builtin_nanf("") : fmaxf(m, other);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = (r != r || red[i] != red[i]) ? __builtin_nanf("") : fmaxf(r, red[i]);
+    out[blockIdx.x] = r;
+  }
+}
+
+// ---- encode: image_util.image_from_spectrogram (:27-54).  mel (N*C, M, T) -> img (N, M, T, 3) uint8.
+// q = uint8(255 - float32(pow(float32(x / max), power)) * 255): monotone non-increasing in the
+// float32 ratio r = x / max, so q = number of thresholds thr[v] (v = 0..254, descending) with
+// r < thr[v], where thr[v] is the smallest float32 r whose numpy result is <= v.
+__global__ void __launch_bounds__(256) image_encode_kernel(const float* __restrict__ mel, const float* __restrict__ clip_max,
+                                                          const float* __restrict__ thr, uint8_t* __restrict__ img, int M,
+                                                          int T, int C, size_t total_px) {
+  __shared__ float thr_s[256];
+  thr_s[threadIdx.x] = threadIdx.x < 255 ? thr[threadIdx.x] : -__builtin_inff();
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pixel index over (N, M, T)
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total_px; i += stride) {
+    const int t = (int)(i % T);
+    const size_t r = i / T;
+    const int h = (int)(r % M);  // image row (already flipped: row h shows mel bin M-1-h)
+    const size_t n = r / M;
+    const float mx = clip_max[n];
+    uint8_t px[3] = {0, 0, 0};
+    for (int c = 0; c < C; ++c) {
+      const float x = mel[((n * C + c) * M + (M - 1 - h)) * T + t];
+      const float ratio = __fdiv_rn(x, mx);
+      // thr_s is descending in v: find the count of v with ratio < thr[v]  (binary search, 8 steps)
+      int lo = 0, hi = 255;  // answer in [0, 255]
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ratio < thr_s[mid]) lo = mid + 1; else hi = mid;
+      }
+      const uint8_t q = (uint8_t)lo;
+      if (C == 1) { px[0] = px[1] = px[2] = q; } else { px[1 + c] = q; }
+    }
+    img[i * 3 + 0] = px[0];
+    img[i * 3 + 1] = px[1];
+    img[i * 3 + 2] = px[2];
+  }
+}
+
+// ---- PCM tail: audio_util.audio_from_waveform (:22-28).  wave (N*C, L) float32 -> pcm (N, L, C) int16,
+// samples * float32(32767 / max|clip|) truncated toward zero.
+__global__ void __launch_bounds__(256) pcm16_kernel(const float* __restrict__ wave, const float* __restrict__ clip_peak,
+                                                   int16_t* __restrict__ pcm, int L, int C, int normalize, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // index over (N, L, C)
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const int l = (int)(r % L);
+    const size_t n = r / L;
+    float v = wave[(n * C + c) * L + l];
+    if (normalize) {
+      // numpy 1.x computes python-int / float32-scalar in float64 and then multiplies the float32
+      // array by that scalar cast to float32
+      const float scale = (float)(32767.0 / (double)clip_peak[n]);
+      v = v * scale;
+    }
+    pcm[i] = (int16_t)(int)v;  // astype(np.int16): truncation toward zero
+  }
+}
+
+static int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out, int N, int H, int W, int C, hipStream_t s) {
+  const size_t total = (size_t)N * C * H * W;
+  hipLaunchKernelGGL(image_decode_kernel, dim3(grid_for(total)), dim3(256), 0, s, img, lut, out, H, W, C, total);
+  return hipGetLastError();
+}
+hipError_t launch_clip_max(const float* x, float* out, int nclips, size_t count, bool abs_value, hipStream_t s) {
+  if (abs_value) hipLaunchKernelGGL(clip_max_kernel<true>, dim3(nclips), dim3(1024), 0, s, x, out, count);
+  else hipLaunchKernelGGL(clip_max_kernel<false>, dim3(nclips), dim3(1024), 0, s, x, out, count);
+  return hipGetLastError();
+}
+hipError_t launch_image_encode(const float* mel, const float* clip_max, const float* thr, uint8_t* img, int N, int M, int T,
+                               int C, hipStream_t s) {
+  const size_t total = (size_t)N * M * T;
+  hipLaunchKernelGGL(image_encode_kernel, dim3(grid_for(total)), dim3(256), 0, s, mel, clip_max, thr, img, M, T, C, total);
+  return hipGetLastError();
+}
+hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s) {
+  const size_t total = (size_t)N * L * C;
+  hipLaunchKernelGGL(pcm16_kernel, dim3(grid_for(total)), dim3(256), 0, s, wave, clip_peak, pcm, L, C, normalize, total);
+  return hipGetLastError();
+}
+
+}  // namespace rfx

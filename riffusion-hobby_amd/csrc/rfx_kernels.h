@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 #include "rfx_core.h"
 
 namespace rfx {
@@ -29,6 +30,7 @@ hipError_t launch_gl_combine(const float* a0, const float* a1, float* out, int B
 // layout conversion between the reference's (B, n_stft, T) tensors and slot-major frames
 hipError_t launch_pack_mag(const float* lin_bft, float* S_slots, int B, int T, hipStream_t stream);
 hipError_t launch_pack_angles(const cf* ang_bft, cf* slots, int B, int T, hipStream_t stream);
+hipError_t launch_unpack_mag(const float* slots, float* out_bft, int B, int T, hipStream_t stream);
 hipError_t launch_unpack_complex(const cf* slots, cf* out_bft, int B, int T, hipStream_t stream);
 
 // forward STFT magnitude of arbitrary-length waveforms: wave [B][Lw] -> mag slots [B*T][kFrameStride]
@@ -42,5 +44,53 @@ struct StftArgs {
   int B, T, Lw, frames_per_block;
 };
 hipError_t launch_stft(const StftArgs& a, hipStream_t stream);
+
+// mel projection GEMM: out[b][m][t] = sum_p fbs[p][m] * mag[b*T+t][p]
+struct MelArgs {
+  const float* mag;     // [N][kFrameStride]
+  const float* fbs;     // [kFrameStride][M] slot-ordered filterbank
+  const int* kblocks;   // indices of the 32-position K blocks that contain a non-zero filterbank row
+  int n_kblocks;
+  float* out;           // [B][M][T]
+  int M, N, T;          // N = B*T frames
+};
+hipError_t launch_mel_gemm(const MelArgs& a, hipStream_t stream);
+
+// banded InverseMelScale SGD (torchaudio 0.13 semantics), one workgroup per frame
+struct ImelTables {
+  const float* csr_w;    // [nnz] filterbank weights, mel-major (column m = bins fs[m] .. fe[m]-1)
+  const int* csr_ptr;    // [M+1]
+  const int* band_lo;    // [M] first bin of mel m's band
+  const int* bin_m0;     // [n_stft] first mel a bin feeds (-1: zero filterbank row)
+  const float* bin_w0;   // [n_stft] weight into mel m0
+  const float* bin_w1;   // [n_stft] weight into mel m0+1 (0 if none)
+  const int* bin_pos;    // [n_stft] slot position of the bin's primary slot
+  const int* bin_pos2;   // [n_stft] slot position of its duplicate slot, or -1
+  int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
+  int nnz;
+};
+struct ImelArgs {
+  ImelTables tb;
+  const float* mel;      // [B][M][T]
+  const float* spec0;    // optional [B][T][n_stft] injected init (reference layout), else seeded RNG
+  float* out_slots;      // [B*T][kFrameStride]
+  float* loss_hist;      // [B*T][max_iter] per-frame sum_m diff^2 before each step
+  const int* it_limit;   // optional [nclips] number of steps to run (fix-up pass), NULL = max_iter
+  int B, M, T, C;        // C = channels per clip (the loss mean couples them)
+  int max_iter;
+  float lr, momentum;
+  unsigned long long seed;
+};
+hipError_t launch_imel(const ImelArgs& a, hipStream_t stream);
+// scans loss_hist for the early-stop condition; it_stop[clip] = steps the reference would have run
+hipError_t launch_imel_scan(const float* loss_hist, int* it_stop, int* any_early, int nclips, int C, int T, int max_iter,
+                            float tol_loss, float tol_change, hipStream_t stream);
+
+// image / PCM codecs
+hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_clip_max(const float* x, float* out, int nclips, size_t count, bool abs_value, hipStream_t s);
+hipError_t launch_image_encode(const float* mel, const float* clip_max, const float* thr, uint8_t* img, int N, int M, int T,
+                               int C, hipStream_t s);
+hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s);
 
 }  // namespace rfx

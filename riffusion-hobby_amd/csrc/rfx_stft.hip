@@ -62,6 +62,26 @@ __global__ void __launch_bounds__(256) unpack_complex_kernel(const cf* __restric
   }
 }
 
+// float slots -> (B, n_stft, T), reading each bin from its primary slot
+__global__ void __launch_bounds__(256) unpack_mag_kernel(const float* __restrict__ slots, float* __restrict__ out, int T) {
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= kBins) return;
+  const int tchunk = blockIdx.y * 16;
+  const int clip = blockIdx.z;
+  int k = bin;
+  if (k % 40 > 20) k = kNfft - k;
+  const int k1 = k % 40, kp = k / 40;
+  const int p = slot_pos_f(k1 * 21 + kp % 21, kp / 21);
+  const int nt = min(16, T - tchunk);
+  for (int i = 0; i < nt; ++i)
+    out[((size_t)clip * kBins + bin) * T + tchunk + i] = slots[((size_t)clip * T + tchunk + i) * kFrameStride + p];
+}
+hipError_t launch_unpack_mag(const float* slots, float* out_bft, int B, int T, hipStream_t stream) {
+  dim3 grid((kBins + 255) / 256, (T + 15) / 16, B);
+  hipLaunchKernelGGL(unpack_mag_kernel, grid, dim3(256), 0, stream, slots, out_bft, T);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_mag(const float* lin_bft, float* S_slots, int B, int T, hipStream_t stream) {
   dim3 grid((kFrameStride + 255) / 256, (T + 15) / 16, B);
   hipLaunchKernelGGL(pack_kernel<false>, grid, dim3(256), 0, stream, (const void*)lin_bft, (void*)S_slots, T);

@@ -65,6 +65,17 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
+    "rfx_unpack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rfx_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "rfx_mel_from_waveform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rfx_inverse_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "rfx_inverse_mel": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_uint64, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "rfx_image_decode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rfx_image_encode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rfx_pcm16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 
@@ -275,6 +286,105 @@ class Plan:
             )
         )
         return out
+
+
+    def unpack_magnitudes(self, slots: torch.Tensor, B: int, Tn: int) -> torch.Tensor:
+        out = torch.empty((B, self.n_stft, Tn), dtype=torch.float32, device=slots.device)
+        check(self.lib.rfx_unpack_magnitudes(self.handle, slots.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        return out
+
+    def mel_from_waveform(self, wave: torch.Tensor) -> torch.Tensor:
+        """spectrogram_converter.py:165-185 on the device: (B, Lw) -> (B, n_mels, T)."""
+        wave = self._chk(wave, torch.float32)
+        B, Lw = wave.shape
+        if Lw <= self.n_fft // 2:
+            raise RuntimeError(
+                f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                f"but got: padding ({self.n_fft // 2}, {self.n_fft // 2}) at dimension 2 of input {list(wave.shape)}"
+            )
+        Tn = 1 + Lw // self.hop_length
+        need = self.lib.rfx_mel_workspace_bytes(self.handle, B, Lw)
+        ws = torch.empty(need, dtype=torch.uint8, device=wave.device)
+        out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=wave.device)
+        check(
+            self.lib.rfx_mel_from_waveform(
+                self.handle, wave.data_ptr(), B, Lw, out.data_ptr(), ws.data_ptr(), ws.numel(), current_stream()
+            )
+        )
+        return out
+
+    def inverse_mel(
+        self,
+        mel: torch.Tensor,
+        channels_per_clip: int,
+        spec0: T.Optional[torch.Tensor] = None,
+        seed: int = 0,
+    ) -> torch.Tensor:
+        """InverseMelScale (SGD): (B, n_mels, T) -> linear magnitudes in slot layout (B*T, stride)."""
+        mel = self._chk(mel, torch.float32)
+        B, M, Tn = mel.shape
+        if M != self.n_mels:
+            raise ValueError(f"Expected an input with {self.n_mels} mel bins. Found: {M}")  # torchaudio's message
+        if spec0 is not None:
+            spec0 = self._chk(spec0, torch.float32)
+            if tuple(spec0.shape) != (B, Tn, self.n_stft):
+                raise ValueError(f"spec0 must be (B, T, n_stft) = {(B, Tn, self.n_stft)}, got {tuple(spec0.shape)}")
+        need = self.lib.rfx_inverse_mel_workspace_bytes(self.handle, B, Tn)
+        ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
+        out = torch.empty((B * Tn, self.frame_stride), dtype=torch.float32, device=mel.device)
+        check(
+            self.lib.rfx_inverse_mel(
+                self.handle,
+                mel.data_ptr(),
+                B,
+                Tn,
+                channels_per_clip,
+                spec0.data_ptr() if spec0 is not None else None,
+                seed & 0xFFFFFFFFFFFFFFFF,
+                out.data_ptr(),
+                ws.data_ptr(),
+                ws.numel(),
+                current_stream(),
+            )
+        )
+        return out
+
+    # ---- codecs (no plan state needed, kept here for one binding site) -------------------------
+    def image_decode(self, img_u8: torch.Tensor, stereo: bool, lut: torch.Tensor) -> torch.Tensor:
+        """(N, H, W, 3) uint8 -> (N*C, H, W) float32."""
+        if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[-1] != 3:
+            raise ValueError("expected (N, H, W, 3) uint8 images")
+        img_u8 = img_u8.contiguous()
+        N, H, W, _ = img_u8.shape
+        C = 2 if stereo else 1
+        out = torch.empty((N * C, H, W), dtype=torch.float32, device=img_u8.device)
+        check(self.lib.rfx_image_decode_u8(img_u8.data_ptr(), N, H, W, int(stereo), lut.data_ptr(), out.data_ptr(), current_stream()))
+        return out
+
+    def image_encode(self, mel: torch.Tensor, stereo: bool, thresholds: torch.Tensor):
+        """(N*C, M, T) float32 -> ((N, M, T, 3) uint8, per-clip max (N,))."""
+        mel = self._chk(mel, torch.float32)
+        C = 2 if stereo else 1
+        NC, M, Tn = mel.shape
+        if NC % C:
+            raise ValueError("batch must be a multiple of the channel count")
+        N = NC // C
+        img = torch.empty((N, M, Tn, 3), dtype=torch.uint8, device=mel.device)
+        mx = torch.empty((N,), dtype=torch.float32, device=mel.device)
+        check(self.lib.rfx_image_encode_u8(mel.data_ptr(), N, M, Tn, int(stereo), thresholds.data_ptr(), mx.data_ptr(), img.data_ptr(), current_stream()))
+        return img, mx
+
+    def pcm16(self, wave: torch.Tensor, channels: int, normalize: bool = True):
+        """(N*C, L) float32 -> ((N, L, C) int16, per-clip peak (N,))."""
+        wave = self._chk(wave, torch.float32)
+        NC, L = wave.shape
+        if NC % channels:
+            raise ValueError("batch must be a multiple of the channel count")
+        N = NC // channels
+        pcm = torch.empty((N, L, channels), dtype=torch.int16, device=wave.device)
+        peak = torch.zeros((N,), dtype=torch.float32, device=wave.device)
+        check(self.lib.rfx_pcm16(wave.data_ptr(), N, channels, L, int(normalize), peak.data_ptr(), pcm.data_ptr(), current_stream()))
+        return pcm, peak
 
 
 _plans: T.Dict[T.Tuple[T.Any, str], Plan] = {}

@@ -1,0 +1,99 @@
+"""
+Spectrogram images <-> audio segments.
+
+Drop-in for the reference's `riffusion/spectrogram_image_converter.py:10-91` (same constructor,
+attributes and the two per-clip methods) plus batch entry points that keep many tiles in flight on
+the GPU: `audio_from_spectrogram_images` takes uint8 tiles in and hands int16 PCM out with one H2D
+and one D2H copy per batch.
+"""
+import typing as T
+
+import numpy as np
+import torch
+from PIL import Image
+
+from riffusion.spectrogram_converter import SpectrogramConverter
+from riffusion.spectrogram_params import SpectrogramParams
+from riffusion.util import audio_util, image_util
+
+
+class SpectrogramImageConverter:
+    def __init__(self, params: SpectrogramParams, device: str = "cuda"):
+        self.p = params
+        self.device = device
+        self.converter = SpectrogramConverter(params=params, device=device)
+
+    # ---- reference API: one clip per call -------------------------------------------------------------
+    def spectrogram_image_from_audio(self, segment: T.Any) -> Image.Image:
+        """Audio segment -> spectrogram image carrying the params (and MAX_VALUE) as EXIF."""
+        assert int(segment.frame_rate) == self.p.sample_rate, "Sample rate mismatch"
+
+        if self.p.stereo:
+            if segment.channels == 1:
+                print("WARNING: Mono audio but stereo=True, cloning channel")
+                segment = segment.set_channels(2)
+            elif segment.channels > 2:
+                print("WARNING: Multi channel audio, reducing to stereo")
+                segment = segment.set_channels(2)
+        else:
+            if segment.channels > 1:
+                print("WARNING: Stereo audio but stereo=False, setting to mono")
+                segment = segment.set_channels(1)
+
+        waveform = np.array([c.get_array_of_samples() for c in segment.split_to_mono()]).astype(np.float32)
+        images, max_values = self.spectrogram_images_from_waveforms(torch.from_numpy(waveform)[None])
+        image = images[0]
+        exif_data = self.p.to_exif()
+        exif_data[SpectrogramParams.ExifTags.MAX_VALUE.value] = float(max_values[0])
+        image.getexif().update(exif_data.items())
+        return image
+
+    def audio_from_spectrogram_image(
+        self,
+        image: Image.Image,
+        apply_filters: bool = True,
+        max_value: float = 30e6,
+    ) -> T.Any:
+        """Spectrogram image -> audio segment (the EXIF MAX_VALUE is not read back, like the reference)."""
+        pcm = self.audio_from_spectrogram_images(
+            np.asarray(image_util.rgb_array_from_image(image))[None], max_value=max_value
+        )
+        segment = audio_util.segment_from_pcm16(pcm[0], self.p.sample_rate)
+        if apply_filters:
+            segment = audio_util.apply_filters(segment, compression=False)
+        return segment
+
+    # ---- batch entry points ------------------------------------------------------------------------------
+    def spectrogram_images_from_waveforms(self, waveforms: torch.Tensor) -> T.Tuple[T.List[Image.Image], np.ndarray]:
+        """(N, C, samples) float waveforms at int16 scale -> N RGB images and their float32 MAX_VALUEs."""
+        conv = self.converter
+        plan = conv._plan()
+        N, C, L = waveforms.shape
+        if C != (2 if self.p.stereo else 1):
+            raise ValueError(f"expected {2 if self.p.stereo else 1} channel(s), got {C}")
+        mel = plan.mel_from_waveform(waveforms.reshape(N * C, L).to(conv.device))
+        thr = torch.from_numpy(image_util.encode_thresholds(float(self.p.power_for_image))).to(conv.device)
+        img, mx = plan.image_encode(mel, self.p.stereo, thr)
+        img_np, mx_np = img.cpu().numpy(), mx.cpu().numpy()
+        return [Image.fromarray(a, mode="RGB") for a in img_np], mx_np
+
+    def audio_from_spectrogram_images(
+        self,
+        images_u8: T.Union[np.ndarray, torch.Tensor],
+        max_value: float = 30e6,
+        seed: T.Optional[int] = None,
+        return_waveform: bool = False,
+    ) -> np.ndarray:
+        """(N, H, W, 3) uint8 RGB tiles -> (N, samples, C) int16 PCM (or the float waveforms)."""
+        conv = self.converter
+        plan = conv._plan()
+        imgs = torch.as_tensor(np.ascontiguousarray(images_u8) if isinstance(images_u8, np.ndarray) else images_u8)
+        imgs = imgs.to(conv.device)
+        C = 2 if self.p.stereo else 1
+        lut = torch.from_numpy(image_util.decode_lut(float(self.p.power_for_image), float(max_value))).to(conv.device)
+        mel = plan.image_decode(imgs, self.p.stereo, lut)
+        wave = conv.waveform_from_mel_amplitudes(mel, seed=seed, channels_per_clip=C)
+        if return_waveform:
+            return wave.reshape(imgs.shape[0], C, -1).cpu().numpy()
+        pcm, _ = plan.pcm16(wave, channels=C, normalize=True)
+        return pcm.cpu().numpy()
