@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""
+bench.py - headline benchmark of the spectrogram -> audio hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): B = 64 synthetic 512x512 mono spectrogram tiles (uint8, already
+resident in HBM) -> image decode -> InverseMelScale (SGD 200) -> Griffin-Lim 32 -> int16 PCM, all in
+HIP kernels through librfx.so.  One "step" = one such batch.  value = tiles/s over all ranks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Clips are independent, so N GPUs each process their own 64 tiles (weak scaling, no data-path
+collective; the only collectives are the timing barrier and the max-over-ranks reduction).
+
+Extra objects on the JSON line:
+  roofline     - the dominant kernel (rfx::gl_iter_kernel<2>, one Griffin-Lim iteration over the
+                 batch): algorithmic bytes per launch = 20 B x 8821 bins x 512 frames x 64 tiles
+                 (|S| 4 B + tprev 8 B read + 8 B written per bin and iteration)
+                 divided by the launch duration measured with HIP events on the launch stream.
+  cpu_baseline - the CPU oracle (oracle/riffusion_oracle.py, a torch-CPU port of the reference's
+                 torchaudio path) timed on this host on ONE tile of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "riffusion-hobby_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+N_BINS, N_FRAMES, N_MELS = 8821, 512, 512
+HOP, SR = 441, 44100
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
+    ap.add_argument("--iters", type=int, default=32, help="Griffin-Lim iterations")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary, or None."""
+    path = os.path.join(ROOT, "profiles", "gl_iter_pmc_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(iters: int, frames: int = 128, threads_cap: int = 16):
+    """
+    The oracle (a torch-CPU port of the reference's torchaudio path) on the host cores, on a BOUNDED
+    sample: a `frames`-wide strip of one synthetic mono tile (cost is linear in the frame count; the
+    SGD loss mean and Griffin-Lim's overlap-add make a strip a faithful 1/8 tile), scaled to tiles/s.
+    Threads are capped: torch's CPU kernels degrade badly when a 256-thread host is oversubscribed.
+    """
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import riffusion_oracle as O  # checker / reported baseline only
+
+    threads = max(1, min(os.cpu_count() or 1, threads_cap))
+    torch.set_num_threads(threads)
+    p = O.OracleParams(num_griffin_lim_iters=iters)
+    rng = np.random.default_rng(20240807)
+    tile = rng.integers(0, 256, size=(N_MELS, frames, 3), dtype=np.uint8)
+    mel = torch.from_numpy(O.spectrogram_from_image_u8(tile, 0.25, False, 30e6))
+    g = torch.Generator().manual_seed(1234)
+    t0 = time.time()
+    lin = O.inverse_mel_scale_sgd(mel, p, generator=g)
+    t1 = time.time()
+    wave = O.griffinlim(lin, p, generator=g)
+    t2 = time.time()
+    O.pcm16_from_waveform(wave.numpy(), normalize=True)
+    total = time.time() - t0
+    frac = frames / float(N_FRAMES)
+    return {
+        "value": round(frac / total, 5),
+        "unit": "tiles/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{frames}-frame strip (1/{N_FRAMES // frames} tile) of one synthetic mono tile: InverseMelScale SGD-200 "
+        f"{t1 - t0:.1f} s + Griffin-Lim {iters} {t2 - t1:.1f} s, scaled linearly to a 512-frame tile "
+        f"(torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} logical cores)",
+        "griffinlim_only_tiles_per_s": round(frac / (t2 - t1), 5),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if distributed else 0)
+    torch.cuda.set_device(dev)
+
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import image_util
+
+    params = SpectrogramParams(num_griffin_lim_iters=args.iters)
+    plan = _hip.get_plan(params, dev)
+    B, T = args.batch, N_FRAMES
+
+    # synthetic tiles of SURVEY.md 8(d), a different seed per rank, resident in HBM before timing
+    rng = np.random.default_rng(20240807 + rank)
+    tiles = torch.from_numpy(rng.integers(0, 256, size=(B, N_MELS, T, 3), dtype=np.uint8)).to(dev)
+    lut = torch.from_numpy(image_util.decode_lut(0.25, 30e6)).to(dev)
+    gl_ws = torch.empty(plan.lib.rfx_griffinlim_workspace_bytes(plan.handle, B, T), dtype=torch.uint8, device=dev)
+
+    def step(seed, launch_ms=None):
+        mel = plan.image_decode(tiles, False, lut)                       # (B, 512, T) float32
+        lin = plan.inverse_mel(mel, 1, seed=seed)                        # slots
+        wave = plan.griffinlim(lin, B, T, args.iters, 0.99, seed=seed + 1, workspace=gl_ws, launch_ms=launch_ms)
+        pcm, _ = plan.pcm16(wave, channels=1, normalize=True)            # (B, L, 1) int16
+        return pcm
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for w in range(args.warmup):
+        step(w)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        pcm = step(100 + k)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(torch.isfinite(pcm.float()).all())
+
+    # ---- roofline leg (outside the timed region): per-launch durations from HIP events on the stream
+    roofline = None
+    extra = {}
+    if rank == 0:
+        ms = (ctypes.c_float * (args.iters + 1))()
+        step(999, launch_ms=ms)
+        steady = [ms[i] for i in range(2, args.iters + 1)] or [ms[-1]]
+        avg_ms = sum(steady) / len(steady)
+        alg_bytes = 20.0 * N_BINS * T * B
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = pmc_traffic_bytes()
+        roofline = {
+            "kernel": "rfx::gl_iter_kernel<2>",
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": round(avg_ms, 4),
+        }
+        # stage split of one step (events through torch on the current stream = the launch stream)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        evs[0].record()
+        mel = plan.image_decode(tiles, False, lut)
+        evs[1].record()
+        lin = plan.inverse_mel(mel, 1, seed=5)
+        evs[2].record()
+        wave = plan.griffinlim(lin, B, T, args.iters, 0.99, seed=6, workspace=gl_ws)
+        evs[3].record()
+        plan.pcm16(wave, channels=1, normalize=True)
+        evs[4].record()
+        torch.cuda.synchronize(dev)
+        names = ["image_decode_ms", "inverse_mel_ms", "griffinlim_ms", "pcm16_ms"]
+        extra = {n: round(evs[i].elapsed_time(evs[i + 1]), 3) for i, n in enumerate(names)}
+        extra["griffinlim_only_tiles_per_s"] = round(B / (extra["griffinlim_ms"] * 1e-3), 1)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    tiles_per_s = world * B * args.steps / elapsed
+    if rank == 0:
+        out = {
+            "metric": "spectrogram_tiles_per_sec_griffinlim32" if args.iters == 32 else f"spectrogram_tiles_per_sec_griffinlim{args.iters}",
+            "value": round(tiles_per_s, 2),
+            "unit": "tiles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batch={B} synthetic 512x512 mono uint8 tiles -> image decode -> InverseMelScale SGD-200 -> "
+                f"Griffin-Lim {args.iters} -> int16 PCM (BASELINE.json configs[1]); tiles resident in HBM",
+                "batch_per_gpu": B,
+                "global_batch": world * B,
+                "griffin_lim_iters": args.iters,
+                "parallelism": f"clips sharded over {world} GPU(s), no data-path collective",
+            },
+            "audio_sec_per_sec": round(tiles_per_s * HOP * (T - 1) / SR, 1),
+            "roofline": roofline,
+            "stages": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.iters)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,14 @@ int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d
                    int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
                    void* stream);
 
+/* Same as rfx_griffinlim, but brackets every kernel launch with HIP events recorded on `stream`
+ * and, after synchronising, writes the n_iter+1 launch durations (ms; [0] = the init ISTFT, [1] the
+ * first iteration, [2..] the steady-state iterations) to the HOST array h_launch_ms.  Measurement
+ * aid for bench.py's roofline figure; it synchronises the stream. */
+int rfx_griffinlim_timed(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                         int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                         void* stream, float* h_launch_ms);
+
 /* slots (float32) -> (B, n_stft, T) float32 */
 int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int T, float* d_bft, void* stream);
 

@@ -300,9 +300,9 @@ size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
   return total;
 }
 
-int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
-                   int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
-                   void* stream_) {
+static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                           int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                           void* stream_, float* h_launch_ms) {
   if (!plan || !d_mag_slots || !d_wave_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_griffinlim: null argument");
   if (B <= 0 || T < 2 || n_iter < 0) return fail(RFX_ERR_INVALID, "rfx_griffinlim: bad shape");
   if (!(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_griffinlim: momentum must be in [0, 1)");
@@ -350,7 +350,15 @@ int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d
   g.audio_in[1] = bufs[3];
   g.audio_out[0] = bufs[0];
   g.audio_out[1] = bufs[1];
+  // optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg)
+  std::vector<hipEvent_t> ev;
+  if (h_launch_ms) {
+    ev.resize(n_iter + 2);
+    for (auto& e : ev) RFX_HIP(hipEventCreate(&e));
+    RFX_HIP(hipEventRecord(ev[0], stream));
+  }
   RFX_HIP(launch_gl_iter(0, g, nblocks, stream));
+  if (h_launch_ms) RFX_HIP(hipEventRecord(ev[1], stream));
   for (int it = 1; it <= n_iter; ++it) {
     g.audio_in[0] = bufs[2 * cur];
     g.audio_in[1] = bufs[2 * cur + 1];
@@ -358,9 +366,30 @@ int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d
     g.audio_out[0] = bufs[2 * cur];
     g.audio_out[1] = bufs[2 * cur + 1];
     RFX_HIP(launch_gl_iter(it == 1 ? 1 : 2, g, nblocks, stream));
+    if (h_launch_ms) RFX_HIP(hipEventRecord(ev[it + 1], stream));
   }
   RFX_HIP(launch_gl_combine(bufs[2 * cur], bufs[2 * cur + 1], d_wave_out, B, L, Lpad, stream));
+  if (h_launch_ms) {
+    RFX_HIP(hipEventSynchronize(ev[n_iter + 1]));
+    for (int i = 0; i <= n_iter; ++i) RFX_HIP(hipEventElapsedTime(&h_launch_ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) hipEventDestroy(e);
+  }
   return RFX_OK;
+}
+
+int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                   int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                   void* stream) {
+  return griffinlim_impl(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace,
+                         workspace_bytes, stream, nullptr);
+}
+
+int rfx_griffinlim_timed(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                         int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                         void* stream, float* h_launch_ms) {
+  if (!h_launch_ms) return fail(RFX_ERR_INVALID, "rfx_griffinlim_timed: null timing array");
+  return griffinlim_impl(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace,
+                         workspace_bytes, stream, h_launch_ms);
 }
 
 int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int T, float* d_bft, void* stream) {

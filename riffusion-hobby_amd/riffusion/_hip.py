@@ -65,6 +65,10 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
+    "rfx_griffinlim_timed": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p],
+    ),
     "rfx_unpack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rfx_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_mel_from_waveform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -264,11 +268,31 @@ class Plan:
         angles0_slots: T.Optional[torch.Tensor] = None,
         seed: int = 0,
         workspace: T.Optional[torch.Tensor] = None,
+        launch_ms: T.Optional[T.Any] = None,
     ) -> torch.Tensor:
         need = self.lib.rfx_griffinlim_workspace_bytes(self.handle, B, Tn)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=mag_slots.device)
         out = torch.empty((B, self.hop_length * (Tn - 1)), dtype=torch.float32, device=mag_slots.device)
+        if launch_ms is not None:  # ctypes float array of n_iter + 1 entries, filled after a stream sync
+            check(
+                self.lib.rfx_griffinlim_timed(
+                    self.handle,
+                    mag_slots.data_ptr(),
+                    angles0_slots.data_ptr() if angles0_slots is not None else None,
+                    seed & 0xFFFFFFFFFFFFFFFF,
+                    B,
+                    Tn,
+                    n_iter,
+                    momentum,
+                    out.data_ptr(),
+                    workspace.data_ptr(),
+                    workspace.numel(),
+                    current_stream(),
+                    ctypes.cast(launch_ms, c_void_p),
+                )
+            )
+            return out
         check(
             self.lib.rfx_griffinlim(
                 self.handle,

@@ -1,0 +1,175 @@
+"""CPU tests of the host-side mirror of the reference interface and of the C-ABI library's surface."""
+import ctypes
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from riffusion.spectrogram_params import SpectrogramParams
+from riffusion.util import audio_util, image_util
+
+
+@pytest.fixture(scope="module")
+def vectors(golden_dir):
+    return np.load(os.path.join(golden_dir, "image_codec_vectors.npz"))
+
+
+# ---- SpectrogramParams ---------------------------------------------------------------------------------
+def test_params_defaults_and_derived_lengths(vectors):
+    p = SpectrogramParams()
+    assert (p.n_fft, p.win_length, p.hop_length) == (17640, 4410, 441)
+    assert (p.num_griffin_lim_iters, p.max_mel_iters, p.power_for_image) == (32, 200, 0.25)
+    sets = ({}, {"stereo": True}, {"sample_rate": 48000}, {"sample_rate": 22050, "step_size_ms": 5},
+            {"min_frequency": 20, "max_frequency": 20000, "num_frequencies": 256})
+    for kw, row in zip(sets, vectors["params_rows"]):  # rows produced by the reference's own class
+        q = SpectrogramParams(**kw)
+        assert [q.n_fft, q.win_length, q.hop_length] == list(row[:3])
+        assert [float(v) for v in q.to_exif().values()] == list(row[3:])
+
+
+def test_params_exif_round_trip_and_hash():
+    p = SpectrogramParams(stereo=True, min_frequency=20, max_frequency=20000)
+    exif = p.to_exif()
+    assert set(exif) == {11000, 11005, 11010, 11020, 11030, 11040, 11050, 11060, 11070}
+    assert SpectrogramParams.from_exif(exif) == p
+    assert hash(p) == hash(SpectrogramParams(stereo=True, min_frequency=20, max_frequency=20000))
+    assert SpectrogramParams.ExifTags.MAX_VALUE.value == 11080
+    with pytest.raises(KeyError):
+        SpectrogramParams.from_exif({11000: 44100})
+    with pytest.raises(Exception):
+        p.stereo = False  # frozen
+
+
+# ---- image codec host side ----------------------------------------------------------------------------
+def test_image_util_equals_reference_vectors(vectors):
+    from PIL import Image
+
+    for tag, C in (("mono", 1), ("stereo", 2)):
+        spec = vectors[f"enc_{tag}_in"]
+        img = image_util.image_from_spectrogram(spec, 0.25)
+        assert img.mode == "RGB" and np.array_equal(np.array(img), vectors[f"enc_{tag}_out"])
+        got = image_util.spectrogram_from_image(img, 0.25, C == 2, 30e6)
+        assert got.dtype == np.float32 and np.array_equal(got, vectors[f"dec_{tag}_30e6"])
+    gray = Image.fromarray(np.arange(256, dtype=np.uint8).reshape(16, 16), mode="L")
+    assert np.array_equal(image_util.spectrogram_from_image(gray, 0.25, False, 30e6), vectors["dec_all256"])
+    ramp = np.linspace(0.0, 1.0, 65536, dtype=np.float32).reshape(1, 256, 256)
+    assert np.array_equal(np.array(image_util.image_from_spectrogram(ramp, 0.25))[..., 0], vectors["enc_ramp_out"])
+    with pytest.raises(NotImplementedError):
+        image_util.image_from_spectrogram(np.ones((3, 4, 4), np.float32))
+
+
+def test_threshold_table_is_consistent():
+    thr = image_util.encode_thresholds(0.25)
+    assert thr.shape == (255,) and np.all(np.diff(thr) <= 0) and thr[0] < 1.0 and thr[-1] > 0.0
+    # each threshold is the first float32 that quantises to <= v: its predecessor quantises to v + 1
+    bits = thr.view(np.uint32)
+    below = (bits - 1).view(np.float32)
+    q_at = image_util._quantise_ratio(thr, 0.25).astype(int)
+    q_below = image_util._quantise_ratio(below, 0.25).astype(int)
+    assert np.all(q_at <= np.arange(255)) and np.all(q_below > np.arange(255))
+
+
+def test_exif_from_image(golden_dir):
+    from PIL import Image
+
+    im = Image.open(os.path.join(golden_dir, "clip_2_start_103694_ms_duration_5678_ms_stereo.png"))
+    tags = image_util.exif_from_image(im)
+    assert tags["MAX_VALUE"] == 46801012.0 and tags["STEREO"] == 1 and tags["SAMPLE_RATE"] == 44100
+    assert SpectrogramParams.from_exif(im.getexif()) == SpectrogramParams(stereo=True)
+    assert image_util.exif_from_image(Image.open(os.path.join(golden_dir, "og_beat_64.png"))) == {}
+
+
+# ---- PCM tail -------------------------------------------------------------------------------------------------
+def test_pcm16_from_waveform_matches_oracle_and_reference_semantics():
+    import riffusion_oracle as O
+
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((2, 1000)) * 3.7).astype(np.float32)
+    a = audio_util.pcm16_from_waveform(x, normalize=True)
+    assert a.dtype == np.int16 and a.shape == (1000, 2)
+    assert np.array_equal(a, O.pcm16_from_waveform(x, normalize=True))
+    assert np.abs(a).max() in (32766, 32767)
+    assert np.array_equal(audio_util.pcm16_from_waveform(np.array([[1.9, -1.9, 0.4]], np.float32)), [[1], [-1], [0]])
+
+
+def test_pcm_segment_interface(golden_dir, tmp_path):
+    seg = audio_util.PcmSegment.from_wav(os.path.join(golden_dir, "clip_2_start_103694_ms_duration_5678_ms.wav"))
+    assert (seg.frame_rate, seg.channels, seg.sample_width) == (44100, 2, 2)
+    assert abs(seg.duration_seconds - 5.678) < 0.001 and abs(len(seg) - 5678) <= 1
+    monos = seg.split_to_mono()
+    assert len(monos) == 2 and len(monos[0].get_array_of_samples()) == 250400
+    assert seg.set_channels(1).channels == 1 and monos[0].set_channels(2).channels == 2
+    out = tmp_path / "x.wav"
+    seg.export(str(out), format="wav")
+    back = audio_util.PcmSegment.from_wav(str(out))
+    assert np.array_equal(back.get_array_of_samples(), seg.get_array_of_samples())
+    made = audio_util.audio_from_waveform(np.ones((1, 50), np.float32), 44100, normalize=True)
+    assert made.frame_rate == 44100 and made.channels == 1
+
+
+# ---- converter surface without a GPU -----------------------------------------------------------------
+def test_converter_constructs_and_refuses_cpu_compute():
+    from riffusion.spectrogram_converter import SpectrogramConverter
+    from riffusion.spectrogram_image_converter import SpectrogramImageConverter
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only behaviour")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        conv = SpectrogramConverter(SpectrogramParams(), device="cuda")
+    assert conv.device == "cpu" and any("not available" in str(x.message) for x in w)
+    for member in ("spectrogram_func", "inverse_spectrogram_func", "mel_scaler", "inverse_mel_scaler"):
+        assert callable(getattr(conv, member))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        conv.mel_amplitudes_from_waveform(torch.zeros(1, 20000))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        conv.waveform_from_mel_amplitudes(torch.zeros(1, 512, 16))
+    ic = SpectrogramImageConverter(SpectrogramParams(), device="cpu")
+    assert ic.p == SpectrogramParams() and ic.device == "cpu" and isinstance(ic.converter, SpectrogramConverter)
+    seg = audio_util.PcmSegment(np.zeros((1000, 1), np.int16), 22050)
+    with pytest.raises(AssertionError):
+        ic.spectrogram_image_from_audio(seg)  # sample-rate mismatch asserts like the reference
+
+
+def test_filterbank_matches_oracle_bitwise():
+    import riffusion_oracle as O
+    from riffusion import _hip
+
+    for kw in ({}, {"min_frequency": 20, "max_frequency": 20000}, {"num_frequencies": 256}):
+        p = SpectrogramParams(**kw)
+        fb = _hip.mel_filterbank(p.n_fft // 2 + 1, float(p.min_frequency), float(p.max_frequency), p.num_frequencies,
+                                 p.sample_rate, p.mel_scale_norm, p.mel_scale_type)
+        assert torch.equal(fb, O.mel_filterbank(O.params_from(p)))
+    assert torch.equal(_hip.hann_window(4410), O.hann_window(O.OracleParams()))
+
+
+# ---- C ABI surface ------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(repo_root):
+    from riffusion import _hip
+
+    header = open(os.path.join(repo_root, "include", "rfx.h")).read()
+    declared = set(re.findall(r"\b(rfx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    lib_path = _hip.library_path()
+    if not os.path.exists(lib_path):
+        import __graft_entry__ as g
+
+        g.build()
+    lib = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.rfx_frame_stride.restype = ctypes.c_int
+    lib.rfx_num_bins.restype = ctypes.c_int
+    assert lib.rfx_frame_stride() == 9408 and lib.rfx_num_bins() == 8821  # no GPU needed for these
+
+
+def test_product_never_imports_the_oracle(repo_root):
+    pkg = os.path.join(repo_root, "riffusion-hobby_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "riffusion_oracle" not in text and "oracle/" not in text.replace("the oracle/", ""), f
