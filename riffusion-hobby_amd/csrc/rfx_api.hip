@@ -188,6 +188,30 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
           const int pos = slot_pos_f(k1 * 21 + ka, kbq);
           if (bin_pos[bin] < 0) bin_pos[bin] = pos; else bin_pos2[bin] = pos;
         }
+    // group formulation (fast kernel): active bins contiguous with no zero row inside, first-filter index
+    // non-decreasing, and the per-thread pairing (short group t, long group M-1-t) fits 8 + 24 registers
+    std::vector<int> grp_start(M + 1, 0);
+    bool fast = ok && M <= 512;
+    if (fast) {
+      int prev = 0;
+      for (int f = f_lo; f < f_hi && fast; ++f) {
+        if (bin_m0[f] < 0 || bin_m0[f] < prev) { fast = false; break; }
+        prev = bin_m0[f];
+      }
+      if (fast) {
+        std::vector<int> cnt(M, 0);
+        for (int f = f_lo; f < f_hi; ++f) cnt[bin_m0[f]]++;
+        int acc = f_lo;
+        for (int g2 = 0; g2 < M; ++g2) { grp_start[g2] = acc; acc += cnt[g2]; }
+        grp_start[M] = acc;
+        for (int t2 = 0; t2 < 256 && fast; ++t2) {
+          const int gH = M - 1 - t2, gL = t2 < M - 256 ? t2 : -1;
+          if (gH >= 0 && cnt[gH] > 24) fast = false;
+          if (gL >= 0 && cnt[gL] > 8) fast = false;
+          if (gL >= 0 && gH >= 0 && gL >= gH) fast = false;
+        }
+      }
+    }
     pl->imel_ok = ok;
     pl->imel_why = why;
     if (ok) {
@@ -196,7 +220,8 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       size_t off = 0;
       auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
       const size_t o_w = take(nnz * 4), o_ptr = take((M + 1) * 4), o_lo = take(M * 4), o_m0 = take(kBins * 4),
-                   o_w0 = take(kBins * 4), o_w1 = take(kBins * 4), o_p = take(kBins * 4), o_p2 = take(kBins * 4);
+                   o_w0 = take(kBins * 4), o_w1 = take(kBins * 4), o_p = take(kBins * 4), o_p2 = take(kBins * 4),
+                   o_gs = take((M + 1) * 4);
       std::vector<char> blob(off);
       memcpy(&blob[o_w], csr_w.data(), nnz * 4);
       memcpy(&blob[o_ptr], csr_ptr.data(), (M + 1) * 4);
@@ -206,6 +231,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       memcpy(&blob[o_w1], bin_w1.data(), kBins * 4);
       memcpy(&blob[o_p], bin_pos.data(), kBins * 4);
       memcpy(&blob[o_p2], bin_pos2.data(), kBins * 4);
+      memcpy(&blob[o_gs], grp_start.data(), (M + 1) * 4);
       RFX_HIP(hipMalloc(&pl->d_imel_blob, off));
       RFX_HIP(hipMemcpy(pl->d_imel_blob, blob.data(), off, hipMemcpyHostToDevice));
       char* d = (char*)pl->d_imel_blob;
@@ -217,6 +243,8 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       pl->imel.bin_w1 = (const float*)(d + o_w1);
       pl->imel.bin_pos = (const int*)(d + o_p);
       pl->imel.bin_pos2 = (const int*)(d + o_p2);
+      pl->imel.grp_start = (const int*)(d + o_gs);
+      pl->imel.fast_ok = fast ? 1 : 0;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;

@@ -18,6 +18,7 @@
 
 #include "rfx_core.h"
 #include "rfx_kernels.h"
+#include <stdlib.h>
 
 namespace rfx {
 
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
   const int n_rounds = (a.M + kImelThreads - 1) / kImelThreads;
   const int up_bound = min(a.M, kImelThreads * ((n_rounds + 1) / 2));
   float melv[kMaxMelPerThread];
-  int mlist[kMaxMelPerThread];
+  int mlist[kMaxMelPerThread], pbeg[kMaxMelPerThread], pend[kMaxMelPerThread], soff[kMaxMelPerThread];
 #pragma unroll
   for (int r = 0; r < kMaxMelPerThread; ++r) {
     int m = -1;
@@ -90,6 +91,9 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
     }
     mlist[r] = m;
     melv[r] = m >= 0 ? a.mel[((size_t)b * a.M + m) * a.T + t] : 0.f;
+    pbeg[r] = m >= 0 ? tb.csr_ptr[m] : 0;
+    pend[r] = m >= 0 ? tb.csr_ptr[m + 1] : 0;
+    soff[r] = m >= 0 ? (tb.band_lo[m] - tb.f_lo) - pbeg[r] : 0;  // spec_s[soff + p] pairs with w_s[p]
   }
   const float gscale = -2.0f / (float)(a.C * a.T);
   __syncthreads();
@@ -101,10 +105,24 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
     for (int r = 0; r < kMaxMelPerThread; ++r) {
       const int m = mlist[r];
       if (m < 0) continue;
-      const int p0 = tb.csr_ptr[m], p1 = tb.csr_ptr[m + 1];
-      const float* sp = spec_s + (tb.band_lo[m] - tb.f_lo);
-      float acc = 0.f;
-      for (int p = p0; p < p1; ++p) acc = fmaf(w_s[p], sp[p - p0], acc);
+      const int p1 = pend[r];
+      const float* sp = spec_s + soff[r];
+      // eight LDS pairs in flight per trip (the band length varies per mel: clamp + zero weight)
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      for (int p = pbeg[r]; p < p1; p += 8) {
+        float w[8], sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int q = min(p + i, p1 - 1);
+          w[i] = (p + i < p1) ? w_s[q] : 0.f;
+          sv[i] = sp[q];
+        }
+        acc0 = fmaf(w[0], sv[0], acc0); acc1 = fmaf(w[1], sv[1], acc1);
+        acc2 = fmaf(w[2], sv[2], acc2); acc3 = fmaf(w[3], sv[3], acc3);
+        acc0 = fmaf(w[4], sv[4], acc0); acc1 = fmaf(w[5], sv[5], acc1);
+        acc2 = fmaf(w[6], sv[6], acc2); acc3 = fmaf(w[7], sv[7], acc3);
+      }
+      const float acc = (acc0 + acc1) + (acc2 + acc3);
       const float d = melv[r] - acc;
       diff_s[m] = d;
       sq = fmaf(d, d, sq);
@@ -153,6 +171,165 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
     for (int i = tid; i < a.max_iter; i += kImelThreads) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? hist_s[i] : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast path: group formulation.  Bins whose first filter is g form group g (contiguous, disjoint):
+//   A_g = sum w0*spec (into filter g)      B_g = sum w1*spec (into filter g+1)      pred_m = A_m + B_{m-1}
+// A thread owns one short low-frequency group and one long high-frequency group with all of their
+// state (spec, momentum buffer, both weights) in registers; per step it publishes A/B (4 LDS
+// writes), crosses ONE barrier, reads its neighbours' B_{g-1} / A_{g+1} (4 LDS reads) and forms the
+// two residuals it needs itself.  Nothing else touches memory inside the 200-step loop.
+// ---------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true);
+  return x + __builtin_bit_cast(float, y);
+}
+// sum over the 64 lanes of a wave (result valid in every lane): 4 DPP adds inside rows of 16 + 4 readlanes
+__device__ __forceinline__ float wave_sum(float x) {
+  x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);  // row_half_mirror
+  x = dpp_add<0x140>(x);  // row_mirror
+  const int xi = __builtin_bit_cast(int, x);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48)));
+}
+
+template <int N>
+struct GroupState {
+  float spec[N], buf[N], w0[N], w1[N];
+  int f0, n;  // first bin, bin count
+};
+
+template <int N>
+__device__ __forceinline__ void group_load(GroupState<N>& g, int grp, const ImelArgs& a, int frame, unsigned long long rbase) {
+  const ImelTables& tb = a.tb;
+  g.f0 = grp >= 0 ? tb.grp_start[grp] : 0;
+  g.n = grp >= 0 ? tb.grp_start[grp + 1] - g.f0 : 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const bool ok = i < g.n;
+    const int f = g.f0 + (ok ? i : 0);
+    g.w0[i] = ok ? tb.bin_w0[f] : 0.f;
+    g.w1[i] = ok ? tb.bin_w1[f] : 0.f;
+    g.spec[i] = ok ? (a.spec0 ? a.spec0[(size_t)frame * kBins + f] : rand_unit(a.seed, rbase + f)) : 0.f;
+    g.buf[i] = 0.f;
+  }
+}
+template <int N>
+__device__ __forceinline__ void group_ab(const GroupState<N>& g, float& A, float& B) {
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; i += 2) {
+    a0 = fmaf(g.w0[i], g.spec[i], a0);
+    b0 = fmaf(g.w1[i], g.spec[i], b0);
+    if (i + 1 < N) {
+      a1 = fmaf(g.w0[i + 1], g.spec[i + 1], a1);
+      b1 = fmaf(g.w1[i + 1], g.spec[i + 1], b1);
+    }
+  }
+  A = a0 + a1;
+  B = b0 + b1;
+}
+template <int N>
+__device__ __forceinline__ void group_step(GroupState<N>& g, float d0, float d1, bool first, float mom, float lr) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float gr = fmaf(d0, g.w0[i], d1 * g.w1[i]);
+    g.buf[i] = first ? gr : fmaf(mom, g.buf[i], gr);
+    g.spec[i] = fmaxf(0.f, fmaf(-lr, g.buf[i], g.spec[i]));
+  }
+}
+template <int N>
+__device__ __forceinline__ void group_store(const GroupState<N>& g, const ImelTables& tb, float* out) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < g.n) {
+      const int f = g.f0 + i;
+      out[tb.bin_pos[f]] = g.spec[i];
+      const int p2 = tb.bin_pos2[f];
+      if (p2 >= 0) out[p2] = g.spec[i];
+    }
+}
+
+template <int NLO, int NHI>
+__global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ImelTables& tb = a.tb;
+  const int M = a.M;
+  float* Ab = reinterpret_cast<float*>(smem);  // [2][M + 2], entry m at index m + 1
+  float* Bb = Ab + 2 * (M + 2);                // [2][M + 2]
+  float* red = Bb + 2 * (M + 2);               // [2][4]
+  float* hist_s = red + 8;                     // [max_iter]
+
+  const int frame = blockIdx.x;
+  const int b = frame / a.T, t = frame - b * a.T;
+  const int clip = b / a.C;
+  const int tid = threadIdx.x;
+  const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
+  if (a.it_limit && steps >= a.max_iter) return;
+  const unsigned long long rbase = (unsigned long long)frame * kBins;
+
+  const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;           // long groups, counted down from the top
+  const int gL = (tid < M - kImelThreads) ? tid : -1;             // short groups, counted up from 0
+  GroupState<NLO> lo;
+  GroupState<NHI> hi;
+  group_load(lo, gL, a, frame, rbase);
+  group_load(hi, gH, a, frame, rbase);
+  auto melat = [&](int m) { return (m >= 0 && m < M) ? a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
+  const float mL0 = gL >= 0 ? melat(gL) : 0.f, mL1 = gL >= 0 ? melat(gL + 1) : 0.f;
+  const float mH0 = gH >= 0 ? melat(gH) : 0.f, mH1 = gH >= 0 ? melat(gH + 1) : 0.f;
+  for (int i = tid; i < 4 * (M + 2); i += kImelThreads) Ab[i] = 0.f;  // Ab and Bb are contiguous: zero both incl. pads
+  const float gscale = -2.0f / (float)(a.C * a.T);
+  __syncthreads();
+
+  for (int it = 0; it < steps; ++it) {
+    const int par = it & 1;
+    float AL, BL, AH, BH;
+    group_ab(lo, AL, BL);
+    group_ab(hi, AH, BH);
+    float* Ap = Ab + par * (M + 2) + 1;
+    float* Bp = Bb + par * (M + 2) + 1;
+    if (gL >= 0) { Ap[gL] = AL; Bp[gL] = BL; }
+    if (gH >= 0) { Ap[gH] = AH; Bp[gH] = BH; }
+    __syncthreads();
+    if (tid == 0 && it > 0) hist_s[it - 1] = (red[(par ^ 1) * 4 + 0] + red[(par ^ 1) * 4 + 1]) + (red[(par ^ 1) * 4 + 2] + red[(par ^ 1) * 4 + 3]);
+    // residuals of the two filters each group feeds: d0 = diff[g], d1 = diff[g+1]
+    const float dL0 = gL >= 0 ? mL0 - AL - Bp[gL - 1] : 0.f;
+    const float dL1 = gL >= 0 ? mL1 - Ap[gL + 1] - BL : 0.f;
+    const float dH0 = gH >= 0 ? mH0 - AH - Bp[gH - 1] : 0.f;
+    const float dH1 = gH >= 0 ? mH1 - Ap[gH + 1] - BH : 0.f;
+    const float sq = wave_sum(fmaf(dL0, dL0, dH0 * dH0));  // every filter's residual is owned exactly once
+    if ((tid & 63) == 0) red[par * 4 + (tid >> 6)] = sq;
+    // the last filter has no successor: its d1 multiplies w1 == 0
+    group_step(lo, gscale * dL0, gscale * dL1, it == 0, a.momentum, a.lr);
+    group_step(hi, gscale * dH0, gscale * dH1, it == 0, a.momentum, a.lr);
+  }
+  __syncthreads();
+  if (tid == 0 && steps > 0) {
+    const int par = (steps - 1) & 1;
+    hist_s[steps - 1] = (red[par * 4 + 0] + red[par * 4 + 1]) + (red[par * 4 + 2] + red[par * 4 + 3]);
+  }
+  __syncthreads();
+
+  float* out = a.out_slots + (size_t)frame * kFrameStride;
+  group_store(lo, tb, out);
+  group_store(hi, tb, out);
+  for (int f = tid; f < kBins; f += kImelThreads) {
+    if (f >= tb.f_lo && f < tb.f_hi) continue;
+    const float v = a.spec0 ? a.spec0[(size_t)frame * kBins + f] : rand_unit(a.seed, rbase + f);
+    out[tb.bin_pos[f]] = v;
+    const int p2 = tb.bin_pos2[f];
+    if (p2 >= 0) out[p2] = v;
+  }
+  for (int p = tid; p < kFrameStride; p += kImelThreads) {
+    int q, kb;
+    if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
+  }
+  if (a.loss_hist && !a.it_limit)
+    for (int i = tid; i < a.max_iter; i += kImelThreads) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? hist_s[i] : 0.f;
+}
+
 // one thread per clip: replays the reference's stopping rule on the clip-mean loss
 __global__ void imel_scan_kernel(const float* __restrict__ loss_hist, int* __restrict__ it_stop, int* __restrict__ any_early,
                                  int nclips, int C, int T, int max_iter, float tol_loss, float tol_change) {
@@ -183,6 +360,11 @@ __global__ void imel_scan_kernel(const float* __restrict__ loss_hist, int* __res
 }
 
 hipError_t launch_imel(const ImelArgs& a, hipStream_t stream) {
+  if (a.tb.fast_ok && !getenv("RFX_IMEL_GENERAL")) {
+    const size_t lds = sizeof(float) * (4 * (a.M + 2) + 8 + a.max_iter);
+    hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
+    return hipGetLastError();
+  }
   const int nb = a.tb.f_hi - a.tb.f_lo;
   const size_t lds = sizeof(float) * (((nb + 3) & ~3) + ((a.tb.nnz + 3) & ~3) + ((a.M + 1 + 3) & ~3) + 4 + a.max_iter);
   const int bpt = (nb + kImelThreads - 1) / kImelThreads;

@@ -66,8 +66,10 @@ struct ImelTables {
   const float* bin_w1;   // [n_stft] weight into mel m0+1 (0 if none)
   const int* bin_pos;    // [n_stft] slot position of the bin's primary slot
   const int* bin_pos2;   // [n_stft] slot position of its duplicate slot, or -1
+  const int* grp_start;  // [M+1] first bin of group g (bins whose first filter is g), fast path only
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
   int nnz;
+  int fast_ok;           // group formulation applicable with <8, 24> bins per thread
 };
 struct ImelArgs {
   ImelTables tb;
