@@ -312,7 +312,7 @@ static void gl_layout(int B, int T, size_t& off_tprev, size_t& off_audio, size_t
   Lpad = (int)align_up((size_t)L, 64);
   size_t o = 0;
   off_tprev = o;
-  o += align_up((size_t)B * T * kFrameStride * sizeof(cf), 256);
+  o += 2 * align_up((size_t)B * T * kFrameStride * sizeof(cf), 256);  // tprev ping-pong
   off_audio = o;
   o += align_up(4 * (size_t)B * Lpad * sizeof(float), 256);
   off_scale = o;
@@ -350,7 +350,9 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
 
   GlArgs g;
   g.S = d_mag_slots;
-  g.tprev = (cf*)(ws + off_tprev);
+  cf* tprev_buf[2] = {(cf*)(ws + off_tprev), (cf*)(ws + off_tprev + align_up((size_t)B * T * kFrameStride * sizeof(cf), 256))};
+  g.tprev_in = tprev_buf[0];
+  g.tprev_out = tprev_buf[1];
   g.angles0 = (const cf*)d_angles0_slots;
   g.out_scale = scale;
   g.tw1 = plan->d_tw1;
@@ -393,6 +395,8 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
     cur ^= 1;
     g.audio_out[0] = bufs[2 * cur];
     g.audio_out[1] = bufs[2 * cur + 1];
+    g.tprev_in = tprev_buf[(it + 1) & 1];   // written by iteration it-1
+    g.tprev_out = tprev_buf[it & 1];
     RFX_HIP(launch_gl_iter(it == 1 ? 1 : 2, g, nblocks, stream));
     if (h_launch_ms) RFX_HIP(hipEventRecord(ev[it + 1], stream));
   }

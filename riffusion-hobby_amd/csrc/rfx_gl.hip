@@ -25,12 +25,15 @@ namespace rfx {
 
 // descriptors of the per-clip streams (wave-uniform, live in SGPRs)
 struct GlStreams {
-  rsrc_t S, tprev, init;  // this clip's slot-major frames
+  rsrc_t S, tprev, tprev_out, init;  // this clip's slot-major frames (tprev is read, tprev_out written)
   bool have_init;
 };
 
 #ifndef RFX_STREAM_AUX
 #define RFX_STREAM_AUX 2  // gfx950 'nt'
+#endif
+#ifndef RFX_STORE_AUX
+#define RFX_STORE_AUX RFX_STREAM_AUX
 #endif
 // The per-bin update streams |S| (4 B) and tprev (8 B) per slot from HBM.  A thread's 21 slots are
 // fetched in three stages whose loads are put in flight well ahead of their use (stage A under
@@ -46,23 +49,35 @@ struct Stage {
 };
 
 template <int MODE, int KB0, int N>
-__device__ __forceinline__ void stage_issue(Stage<KB0, N>& g, const GlStreams& st, unsigned foff, unsigned q) {
+__device__ __forceinline__ void stage_issue(Stage<KB0, N>& g, const GlStreams& st, unsigned foff, unsigned q16) {
   constexpr int NB = (KB0 + N == 21) ? N - 1 : N;  // kb handled by 16-B loads
 #pragma unroll
-  for (int i = 0; i < NB / 4; ++i) g.s4[i] = ld4<RFX_STREAM_AUX>(st.S, q * 16u, foff + (unsigned)(KB0 / 4 + i) * (kQPad * 16u));
-  if (KB0 + N == 21) g.s_tail = ld1<RFX_STREAM_AUX>(st.S, q * 4u, foff + 20u * kQPad * 4u);
+  for (int i = 0; i < NB / 4; ++i) g.s4[i] = ld4<RFX_STREAM_AUX>(st.S, q16, foff + (unsigned)(KB0 / 4 + i) * (kQPad * 16u));
+  if (KB0 + N == 21) g.s_tail = ld1<RFX_STREAM_AUX>(st.S, q16 >> 2, foff + 20u * kQPad * 4u);
   if (MODE == 2 || (MODE == 0 && st.have_init)) {
     const rsrc_t src = (MODE == 0) ? st.init : st.tprev;
 #pragma unroll
-    for (int i = 0; i < NB / 2; ++i) g.t4[i] = ld4<RFX_STREAM_AUX>(src, q * 16u, 2u * foff + (unsigned)(KB0 / 2 + i) * (kQPad * 16u));
-    if (KB0 + N == 21) g.t_tail = ld2<RFX_STREAM_AUX>(src, q * 8u, 2u * foff + 20u * kQPad * 8u);
+    for (int i = 0; i < NB / 2; ++i) g.t4[i] = ld4<RFX_STREAM_AUX>(src, q16, 2u * foff + (unsigned)(KB0 / 2 + i) * (kQPad * 16u));
+    if (KB0 + N == 21) g.t_tail = ld2<RFX_STREAM_AUX>(src, q16 >> 1, 2u * foff + 20u * kQPad * 8u);
   }
 }
 
+// tprev_out <- rebuilt for the whole thread (11 stores).  Issued in ONE burst right after the first
+// stage's loads: gfx950's vmcnt retires loads and stores in issue order, so a store issued between
+// two load stages would put its full HBM write latency in front of the second stage's data.  The
+// burst precedes the later stages' tprev loads, hence the ping-pong: it never writes the buffer
+// this launch reads.
+__device__ __forceinline__ void store_rebuilt(const cf (&R)[21], const GlStreams& st, unsigned foff, unsigned q16) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+    st4<RFX_STORE_AUX>(v4f{R[2 * i].re, R[2 * i].im, R[2 * i + 1].re, R[2 * i + 1].im}, st.tprev_out, q16,
+                       2u * foff + (unsigned)i * (kQPad * 16u));
+  st2<RFX_STORE_AUX>(v2f{R[20].re, R[20].im}, st.tprev_out, q16 >> 1, 2u * foff + 20u * kQPad * 8u);
+}
+
 template <int MODE, int KB0, int N>
-__device__ __forceinline__ void stage_apply(cf (&R)[21], const Stage<KB0, N>& g, const GlStreams& st, unsigned foff,
-                                            unsigned q, bool active, float mom, unsigned long long seed,
-                                            unsigned long long rng_base, int k1, int ka) {
+__device__ __forceinline__ void stage_apply(cf (&R)[21], const Stage<KB0, N>& g, const GlStreams& st, float mom,
+                                            unsigned long long seed, unsigned long long rng_base, int k1, int ka) {
   constexpr int NB = (KB0 + N == 21) ? N - 1 : N;
   float Sm[N];
   cf tp[N];
@@ -88,16 +103,6 @@ __device__ __forceinline__ void stage_apply(cf (&R)[21], const Stage<KB0, N>& g,
 #pragma unroll
     for (int i = 0; i < N; ++i) R[KB0 + i] = cf{Sm[i] * tp[i].re, Sm[i] * tp[i].im};
   } else {
-#ifndef RFX_ABL_NOMEM
-    // tprev <- rebuilt (before R is overwritten by the next spectrum estimate)
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < NB / 2; ++i)
-        st4<RFX_STREAM_AUX>(v4f{R[KB0 + 2 * i].re, R[KB0 + 2 * i].im, R[KB0 + 2 * i + 1].re, R[KB0 + 2 * i + 1].im}, st.tprev,
-                    q * 16u, 2u * foff + (unsigned)(KB0 / 2 + i) * (kQPad * 16u));
-      if (KB0 + N == 21) st2<RFX_STREAM_AUX>(v2f{R[20].re, R[20].im}, st.tprev, q * 8u, 2u * foff + 20u * kQPad * 8u);
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const cf prev = (MODE == 1) ? cf{0.f, 0.f} : tp[i];
@@ -122,9 +127,10 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   const size_t clip_slots = (size_t)g.T * kFrameStride;
   GlStreams st;
   st.S = make_rsrc(g.S + clip * clip_slots, clip_slots * sizeof(float));
-  st.tprev = make_rsrc(g.tprev + clip * clip_slots, clip_slots * sizeof(cf));
+  st.tprev = make_rsrc(g.tprev_in + clip * clip_slots, clip_slots * sizeof(cf));
+  st.tprev_out = make_rsrc(g.tprev_out + clip * clip_slots, clip_slots * sizeof(cf));
   st.have_init = g.angles0 != nullptr;
-  st.init = make_rsrc(st.have_init ? g.angles0 + clip * clip_slots : g.tprev, clip_slots * sizeof(cf));
+  st.init = make_rsrc(st.have_init ? g.angles0 + clip * clip_slots : g.tprev_in, clip_slots * sizeof(cf));
   const rsrc_t in0 = make_rsrc(g.audio_in[0] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t in1 = make_rsrc(g.audio_in[1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t outA = make_rsrc(g.audio_out[par] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
@@ -155,7 +161,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #endif
   for (int fr = t0; fr <= t1; ++fr) {
     const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
-    const unsigned q = threadIdx.x;  // padded owner index of the slot streams
+    const unsigned q16 = threadIdx.x * 16u;  // byte offset of this thread's 16-B slot pairs/quads in the streams
     const unsigned long long rng_base = ((unsigned long long)clip * g.T + fr) * kBins;
 
     cf R[21];
@@ -166,7 +172,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #define RFX_SPLIT_B 8
 #endif
 #ifndef RFX_EARLY_ISSUE
-#define RFX_EARLY_ISSUE 0  // 1: put stage A in flight under P2/P3 (needs a spill-free build to pay off)
+#define RFX_EARLY_ISSUE 1  // stage A goes in flight right after the analysis barrier, under P2/P3
 #endif
 #ifndef RFX_STREAM_AUX
 #define RFX_STREAM_AUX 2
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
     Stage<RFX_SPLIT_A + RFX_SPLIT_B, 21 - RFX_SPLIT_A - RFX_SPLIT_B> sc;
     auto issue_a = [&] {
 #if !defined(RFX_ABL_NOMEM) && RFX_EARLY_ISSUE
-      stage_issue<MODE>(sa, st, foff, q);
+      stage_issue<MODE>(sa, st, foff, q16);
 #endif
     };
     if (MODE != 0) {
@@ -198,35 +204,31 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
     } else {
       issue_a();
     }
-    // ---- momentum phase update; R becomes the next spectrum estimate
+    // ---- momentum phase update; R becomes the next spectrum estimate.  Order of VMEM issue:
+    // stage A loads, ALL tprev stores, stage B loads | apply A | stage C loads | apply B | apply C
 #ifdef RFX_ABL_NOMEM
 #pragma unroll
     for (int i = 0; i < 2; ++i) { sa.s4[i] = v4f{1.f, 2.f, 3.f, 4.f}; sb.s4[i] = v4f{1.f, 2.f, 3.f, 4.f}; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { sa.t4[i] = v4f{.1f, .2f, .3f, .4f}; sb.t4[i] = v4f{.1f, .2f, .3f, .4f}; }
     sc.s4[0] = v4f{1.f, 2.f, 3.f, 4.f}; sc.t4[0] = sc.t4[1] = v4f{.1f, .2f, .3f, .4f}; sc.s_tail = 2.f; sc.t_tail = v2f{.3f, .1f};
-#elif RFX_EARLY_ISSUE
-    stage_issue<MODE>(sb, st, foff, q);
-    RFX_SCHED_FENCE();
 #else
-    stage_issue<MODE>(sa, st, foff, q);
+#if !RFX_EARLY_ISSUE
+    stage_issue<MODE>(sa, st, foff, q16);
 #endif
-    stage_apply<MODE>(R, sa, st, foff, q, t.active, g.mom, g.seed, rng_base, t.k1, t.idx);
+    if (MODE != 0 && t.active) store_rebuilt(R, st, foff, q16);
+    stage_issue<MODE>(sb, st, foff, q16);
+    RFX_SCHED_FENCE();
+#endif
+    stage_apply<MODE>(R, sa, st, g.mom, g.seed, rng_base, t.k1, t.idx);
+    RFX_SCHED_FENCE();
 #ifndef RFX_ABL_NOMEM
-    RFX_SCHED_FENCE();
-#if RFX_EARLY_ISSUE
-    stage_issue<MODE>(sc, st, foff, q);
-#else
-    stage_issue<MODE>(sb, st, foff, q);
-#endif
+    stage_issue<MODE>(sc, st, foff, q16);
     RFX_SCHED_FENCE();
 #endif
-    stage_apply<MODE>(R, sb, st, foff, q, t.active, g.mom, g.seed, rng_base, t.k1, t.idx);
+    stage_apply<MODE>(R, sb, st, g.mom, g.seed, rng_base, t.k1, t.idx);
     RFX_SCHED_FENCE();
-#if !defined(RFX_ABL_NOMEM) && !RFX_EARLY_ISSUE
-    stage_issue<MODE>(sc, st, foff, q);
-#endif
-    stage_apply<MODE>(R, sc, st, foff, q, t.active, g.mom, g.seed, rng_base, t.k1, t.idx);
+    stage_apply<MODE>(R, sc, st, g.mom, g.seed, rng_base, t.k1, t.idx);
     RFX_SCHED_FENCE();
     RFX_STAMP(3);
 

@@ -9,7 +9,8 @@ namespace rfx {
 
 struct GlArgs {
   const float* S;        // [B*T][kFrameStride] magnitudes, slot_pos_f order
-  cf* tprev;             // [B*T][kFrameStride] previous rebuilt spectrum, slot_pos_c order
+  const cf* tprev_in;    // [B*T][kFrameStride] rebuilt spectrum of the previous iteration, slot_pos_c order
+  cf* tprev_out;         // where this iteration's rebuilt spectrum goes (ping-pong: never the buffer being read)
   const cf* angles0;     // optional injected initial angles, slot_pos_c order (MODE 0)
   const float* audio_in[2];   // parity partial sums of the previous iteration, [B][Lpad]
   float* audio_out[2];
