@@ -334,6 +334,11 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   if (!plan || !d_mag_slots || !d_wave_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_griffinlim: null argument");
   if (B <= 0 || T < 2 || n_iter < 0) return fail(RFX_ERR_INVALID, "rfx_griffinlim: bad shape");
   if (!(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_griffinlim: momentum must be in [0, 1)");
+  // every iteration re-analyses the hop*(T-1)-sample estimate with torch.stft(center=True, reflect):
+  // the reference raises there unless the signal is longer than the n_fft/2 padding
+  if (n_iter > 0 && kHop * (T - 1) <= kNfft / 2)
+    return fail(RFX_ERR_INVALID, "rfx_griffinlim: Padding size should be less than the corresponding input dimension "
+                                 "(reflect padding 8820 needs more than 8820 samples, i.e. at least 22 frames)");
   hipStream_t stream = (hipStream_t)stream_;
   size_t off_tprev, off_audio, off_scale, total;
   int Lpad;

@@ -1,0 +1,116 @@
+"""GPU tests of the boundary contract: errors, re-entrancy, plan cache, edge shapes."""
+import ctypes
+import time
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synthetic_tiles_u8, synthetic_wave
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def params():
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    return SpectrogramParams()
+
+
+def test_plan_cache_and_cheap_construction(params):
+    from riffusion import _hip
+    from riffusion.spectrogram_converter import SpectrogramConverter
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    SpectrogramConverter(params, device="cuda")._plan()
+    assert _hip.get_plan(params, "cuda") is _hip.get_plan(SpectrogramParams(), "cuda")
+    t0 = time.perf_counter()
+    for _ in range(50):  # the reference's server builds a converter per request (server.py:159)
+        SpectrogramConverter(SpectrogramParams(), device="cuda")._plan()
+    assert (time.perf_counter() - t0) / 50 < 2e-3
+
+
+def test_errors_match_reference_behaviour(params):
+    from riffusion import _hip
+    from riffusion.spectrogram_converter import SpectrogramConverter
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    conv = SpectrogramConverter(params, device="cuda")
+    with pytest.raises(RuntimeError, match="Padding size should be less than"):  # torch.stft's reflect-pad error
+        conv.mel_amplitudes_from_waveform(torch.zeros(1, 8820))
+    conv.mel_amplitudes_from_waveform(torch.zeros(1, 8821))  # smallest legal input
+    with pytest.raises(ValueError, match="mel bins"):  # torchaudio InverseMelScale's check
+        conv.waveform_from_mel_amplitudes(torch.zeros(1, 100, 16))
+    with pytest.raises(_hip.RfxError, match="geometry"):
+        SpectrogramConverter(SpectrogramParams(sample_rate=48000), device="cuda").mel_amplitudes_from_waveform(torch.zeros(1, 30000))
+    plan = _hip.get_plan(params, "cuda")
+    with pytest.raises(_hip.RfxError, match="multiple of channels_per_clip"):
+        plan.inverse_mel(torch.zeros(3, 512, 8, device="cuda"), 2)
+    # too small a workspace is an error code, not a crash
+    S = torch.zeros(2 * 24, plan.frame_stride, device="cuda")
+    out = torch.empty(2, 441 * 23, device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    rc = plan.lib.rfx_griffinlim(plan.handle, S.data_ptr(), None, 0, 2, 24, 2, ctypes.c_float(0.99), out.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _hip.current_stream())
+    assert rc == -3 and b"workspace" in plan.lib.rfx_last_error()
+
+
+def test_edge_shapes(params):
+    """Shortest legal clips (22 frames: reflect padding needs > 8820 samples), odd batches, and the
+    reference's own failure below that."""
+    import riffusion_oracle as O
+    from riffusion import _hip
+
+    plan = _hip.get_plan(params, "cuda")
+    op = O.params_from(params)
+    with pytest.raises(_hip.RfxError, match="Padding size should be less than"):
+        plan.griffinlim(torch.zeros(10, plan.frame_stride, device="cuda"), 1, 10, 2, 0.99)
+    with pytest.raises(RuntimeError, match="Padding size should be less than"):
+        O.griffinlim(torch.rand(1, op.n_stft, 10), op, n_iter=2)
+    # zero iterations = one ISTFT: legal for any T >= 2
+    g = torch.Generator().manual_seed(0)
+    mag = torch.rand(1, op.n_stft, 2, generator=g)
+    a0 = torch.rand(1, op.n_stft, 2, dtype=torch.complex64, generator=g)
+    ref0 = O.griffinlim(mag, op, angles0=a0, n_iter=0)
+    got0 = plan.griffinlim(plan.pack_magnitudes(mag.cuda()), 1, 2, 0, 0.99, angles0_slots=plan.pack_complex(a0.cuda())).cpu()
+    assert got0.shape == ref0.shape == (1, 441) and (got0 - ref0).abs().max() / ref0.abs().max() < 1e-5
+    for T, B in ((22, 1), (23, 3), (31, 2)):
+        g = torch.Generator().manual_seed(T)
+        mag = torch.rand(B, op.n_stft, T, generator=g) * 100
+        a0 = torch.rand(B, op.n_stft, T, dtype=torch.complex64, generator=g)
+        ref = O.griffinlim(mag, op, angles0=a0, n_iter=2)
+        got = plan.griffinlim(plan.pack_magnitudes(mag.cuda()), B, T, 2, 0.99, angles0_slots=plan.pack_complex(a0.cuda())).cpu()
+        assert got.shape == ref.shape == (B, 441 * (T - 1))
+        assert (got - ref).abs().max() / ref.abs().max() < 1e-4
+
+
+def test_shared_converter_is_reentrant(params):
+    """One converter used from a ThreadPool, as the reference's batch CLI does (cli.py:172-204)."""
+    from riffusion.spectrogram_image_converter import SpectrogramImageConverter
+
+    ic = SpectrogramImageConverter(params, device="cuda")
+    tiles = synthetic_tiles_u8(6, 512, 24, seed=3)
+
+    def job(i):
+        return ic.audio_from_spectrogram_images(tiles[i : i + 1], seed=100 + i)
+
+    serial = [job(i) for i in range(6)]
+    with ThreadPool(3) as pool:
+        threaded = pool.map(job, range(6))
+    for a, b in zip(serial, threaded):
+        assert np.array_equal(a, b)
+    # and seeds matter / repeat
+    assert not np.array_equal(serial[0], ic.audio_from_spectrogram_images(tiles[0:1], seed=999))
+    assert np.array_equal(serial[0], ic.audio_from_spectrogram_images(tiles[0:1], seed=100))
+
+
+def test_forward_batch_equals_per_clip(params):
+    from riffusion import _hip
+
+    plan = _hip.get_plan(params, "cuda")
+    wave = synthetic_wave(5, 441 * 37 + 100, seed=12).cuda()
+    full = plan.mel_from_waveform(wave)
+    for i in range(5):
+        assert torch.equal(full[i : i + 1], plan.mel_from_waveform(wave[i : i + 1]))
