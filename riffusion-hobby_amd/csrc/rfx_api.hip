@@ -307,14 +307,14 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
   return RFX_OK;
 }
 
-static void gl_layout(int B, int T, size_t& off_tprev, size_t& off_audio, size_t& off_scale, size_t& total, int& Lpad) {
+// Griffin-Lim workspace: three generations (x_{k-1}, x_k, x_{k+1}) of the two parity audio buffers, and the
+// istft normalisation table.  No spectral state is kept between iterations (see rfx_gl.hip).
+static void gl_layout(int B, int T, size_t& off_audio, size_t& off_scale, size_t& total, int& Lpad) {
   const int L = kHop * (T - 1);
   Lpad = (int)align_up((size_t)L, 64);
   size_t o = 0;
-  off_tprev = o;
-  o += 2 * align_up((size_t)B * T * kFrameStride * sizeof(cf), 256);  // tprev ping-pong
   off_audio = o;
-  o += align_up(4 * (size_t)B * Lpad * sizeof(float), 256);
+  o += align_up(6 * (size_t)B * Lpad * sizeof(float), 256);
   off_scale = o;
   o += align_up((size_t)Lpad * sizeof(float), 256);
   total = o;
@@ -322,9 +322,9 @@ static void gl_layout(int B, int T, size_t& off_tprev, size_t& off_audio, size_t
 
 size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
   if (!plan || B <= 0 || T < 2) return 0;
-  size_t a, b, c, total;
+  size_t a, c, total;
   int Lpad;
-  gl_layout(B, T, a, b, c, total, Lpad);
+  gl_layout(B, T, a, c, total, Lpad);
   return total;
 }
 
@@ -340,14 +340,16 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
     return fail(RFX_ERR_INVALID, "rfx_griffinlim: Padding size should be less than the corresponding input dimension "
                                  "(reflect padding 8820 needs more than 8820 samples, i.e. at least 22 frames)");
   hipStream_t stream = (hipStream_t)stream_;
-  size_t off_tprev, off_audio, off_scale, total;
+  size_t off_audio, off_scale, total;
   int Lpad;
-  gl_layout(B, T, off_tprev, off_audio, off_scale, total, Lpad);
+  gl_layout(B, T, off_audio, off_scale, total, Lpad);
   if (workspace_bytes < total) return fail(RFX_ERR_WORKSPACE, "rfx_griffinlim: workspace too small");
   const int L = kHop * (T - 1);
   char* ws = (char*)d_workspace;
   float* audio = (float*)(ws + off_audio);
-  float* bufs[4] = {audio, audio + (size_t)B * Lpad, audio + 2 * (size_t)B * Lpad, audio + 3 * (size_t)B * Lpad};
+  float* gen[3][2];
+  for (int i = 0; i < 3; ++i)
+    for (int p = 0; p < 2; ++p) gen[i][p] = audio + (size_t)(2 * i + p) * B * Lpad;
   float* scale = (float*)(ws + off_scale);
 
   hipLaunchKernelGGL(out_scale_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, plan->d_win, scale, T, L);
@@ -355,9 +357,6 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
 
   GlArgs g;
   g.S = d_mag_slots;
-  cf* tprev_buf[2] = {(cf*)(ws + off_tprev), (cf*)(ws + off_tprev + align_up((size_t)B * T * kFrameStride * sizeof(cf), 256))};
-  g.tprev_in = tprev_buf[0];
-  g.tprev_out = tprev_buf[1];
   g.angles0 = (const cf*)d_angles0_slots;
   g.out_scale = scale;
   g.tw1 = plan->d_tw1;
@@ -380,11 +379,6 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   g.nruns = nruns;
   const int nblocks = B * nruns;
 
-  int cur = 0;  // buffers {0,1} or {2,3}
-  g.audio_in[0] = bufs[2];
-  g.audio_in[1] = bufs[3];
-  g.audio_out[0] = bufs[0];
-  g.audio_out[1] = bufs[1];
   // optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg)
   std::vector<hipEvent_t> ev;
   if (h_launch_ms) {
@@ -392,20 +386,25 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
     for (auto& e : ev) RFX_HIP(hipEventCreate(&e));
     RFX_HIP(hipEventRecord(ev[0], stream));
   }
+  // generation indices: x_k lives in gen[k % 3]
+  auto set_io = [&](int k_in, int k_prev, int k_out) {
+    for (int p = 0; p < 2; ++p) {
+      g.audio_in[p] = gen[k_in][p];
+      g.audio_prev[p] = gen[k_prev][p];
+      g.audio_out[p] = gen[k_out][p];
+    }
+  };
+  set_io(1, 2, 0);  // MODE 0 reads nothing; writes x_0
   RFX_HIP(launch_gl_iter(0, g, nblocks, stream));
   if (h_launch_ms) RFX_HIP(hipEventRecord(ev[1], stream));
   for (int it = 1; it <= n_iter; ++it) {
-    g.audio_in[0] = bufs[2 * cur];
-    g.audio_in[1] = bufs[2 * cur + 1];
-    cur ^= 1;
-    g.audio_out[0] = bufs[2 * cur];
-    g.audio_out[1] = bufs[2 * cur + 1];
-    g.tprev_in = tprev_buf[(it + 1) & 1];   // written by iteration it-1
-    g.tprev_out = tprev_buf[it & 1];
+    // iteration `it` analyses x_{it-1} - m*x_{it-2} and writes x_it
+    set_io((it - 1) % 3, (it + 1) % 3 /* == (it-2) mod 3 */, it % 3);
     RFX_HIP(launch_gl_iter(it == 1 ? 1 : 2, g, nblocks, stream));
     if (h_launch_ms) RFX_HIP(hipEventRecord(ev[it + 1], stream));
   }
-  RFX_HIP(launch_gl_combine(bufs[2 * cur], bufs[2 * cur + 1], d_wave_out, B, L, Lpad, stream));
+  const int last = n_iter % 3;
+  RFX_HIP(launch_gl_combine(gen[last][0], gen[last][1], d_wave_out, B, L, Lpad, stream));
   if (h_launch_ms) {
     RFX_HIP(hipEventSynchronize(ev[n_iter + 1]));
     for (int i = 0; i <= n_iter; ++i) RFX_HIP(hipEventElapsedTime(&h_launch_ms[i], ev[i], ev[i + 1]));

@@ -322,20 +322,21 @@ RFX_HD void p3_inverse(cf* cube, cf (&Z)[21], TW tw2, int k1, int ka) {
 
 // ------------------------------------------------------------------------------------------------
 // Griffin-Lim per-bin update (torchaudio functional.griffinlim loop body):
-//   angles = rebuilt - m*tprev ; angles /= (|angles| + 1e-16) ; tprev = rebuilt ; next = S*angles
+//   angles = rebuilt - m*tprev ; angles /= (|angles| + 1e-16) ; next = S*angles
+// `a` below is already rebuilt - m*tprev: the STFT is linear, so the kernels analyse the signal
+// x_k - m*x_{k-1} instead of subtracting two spectra (see rfx_gl.hip).
 // ------------------------------------------------------------------------------------------------
-RFX_HD cf gl_update(cf rebuilt, cf tprev, float mom, float S) {
-  const float ar = fmaf(-mom, tprev.re, rebuilt.re), ai = fmaf(-mom, tprev.im, rebuilt.im);
+RFX_HD cf gl_project(cf a, float S) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sqrt / divide expansions (~10 VALU
   // instructions per bin); the difference is below the fp32 noise Griffin-Lim amplifies anyway
-  const float mag = __builtin_amdgcn_sqrtf(fmaf(ar, ar, ai * ai));
+  const float mag = __builtin_amdgcn_sqrtf(fmaf(a.re, a.re, a.im * a.im));
   const float sc = S * __builtin_amdgcn_rcpf(mag + 1e-16f);
 #else
-  const float mag = sqrtf(fmaf(ar, ar, ai * ai));
+  const float mag = sqrtf(fmaf(a.re, a.re, a.im * a.im));
   const float sc = S / (mag + 1e-16f);
 #endif
-  return cf{ar * sc, ai * sc};
+  return cf{a.re * sc, a.im * sc};
 }
 
 // counter-based uniform [0,1) pair for the rand_init of Griffin-Lim (stand-in for torch.rand, whose

@@ -8,12 +8,11 @@
 namespace rfx {
 
 struct GlArgs {
-  const float* S;        // [B*T][kFrameStride] magnitudes, slot_pos_f order
-  const cf* tprev_in;    // [B*T][kFrameStride] rebuilt spectrum of the previous iteration, slot_pos_c order
-  cf* tprev_out;         // where this iteration's rebuilt spectrum goes (ping-pong: never the buffer being read)
-  const cf* angles0;     // optional injected initial angles, slot_pos_c order (MODE 0)
-  const float* audio_in[2];   // parity partial sums of the previous iteration, [B][Lpad]
-  float* audio_out[2];
+  const float* S;             // [B*T][kFrameStride] magnitudes, slot_pos_f order
+  const cf* angles0;          // optional injected initial angles, slot_pos_c order (MODE 0)
+  const float* audio_in[2];   // parity partial sums of x_k, the current estimate, [B][Lpad]
+  const float* audio_prev[2]; // parity partial sums of x_{k-1} (MODE 2)
+  float* audio_out[2];        // x_{k+1}
   const float* out_scale;     // [L]  (2/N) / window-envelope  (torch.istft's division by sum w^2)
   const cf* tw1;              // [21][441]
   const cf* tw2;              // [21][21]
