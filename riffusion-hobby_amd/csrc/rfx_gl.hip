@@ -81,6 +81,21 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #pragma unroll
   for (int j = 0; j < 10; ++j) acc[j] = 0.f;
 
+  // analysis input d = x_k - m*x_{k-1} of thread n' for hop blocks fr-5 .. fr+4: a register sliding
+  // window like `acc` (the reflect-padded signal is a fixed function of the padded position, so the
+  // value a frame needs for block beta is the one its predecessor loaded): 4 loads per frame, not 40
+  auto load_d = [&](int blk) {
+    const unsigned p4 = (unsigned)reflect_index(blk * kHop + t.npr, g.L) * 4u;
+    float x = ld1(in0, p4, 0) + ld1(in1, p4, 0);
+    if (MODE == 2) x = fmaf(-g.mom, ld1(pv0, p4, 0) + ld1(pv1, p4, 0), x);
+    return x;
+  };
+  float d[10];
+  if (MODE != 0) {
+#pragma unroll
+    for (int j = 1; j < 10; ++j) d[j] = load_d(t0 + j - 1 - kHalfHops);  // blocks of frame t0-1 shifted in below
+  }
+
   auto emit = [&](int blk, float val) {
     if (blk < 0 || blk >= nblk || !t.active) return;  // blk is wave-uniform
     const unsigned boff = (unsigned)blk * (kHop * 4u);
@@ -107,12 +122,10 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
       // ---- analysis of x_k - m*x_{k-1}: reflect-padded, Hann-windowed frame centred on sample 441*fr
       float u[10];
 #pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        const unsigned p4 = (unsigned)reflect_index((fr + j - kHalfHops) * kHop + t.npr, g.L) * 4u;
-        float x = ld1(in0, p4, 0) + ld1(in1, p4, 0);
-        if (MODE == 2) x = fmaf(-g.mom, ld1(pv0, p4, 0) + ld1(pv1, p4, 0), x);
-        u[j] = x * ld1(win, npr4, (unsigned)j * (kHop * 4u));
-      }
+      for (int j = 0; j < 9; ++j) d[j] = d[j + 1];
+      d[9] = load_d(fr + 9 - kHalfHops);
+#pragma unroll
+      for (int j = 0; j < 10; ++j) u[j] = d[j] * ld1(win, npr4, (unsigned)j * (kHop * 4u));
 #ifdef RFX_ABL_NOFFT
       mag_issue(mag, Ssrc, foff, q16);
 #pragma unroll
