@@ -330,8 +330,20 @@ RFX_HD cf gl_project(cf a, float S) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sqrt / divide expansions (~10 VALU
   // instructions per bin); the difference is below the fp32 noise Griffin-Lim amplifies anyway
+#ifdef RFX_PROJECT_RSQ
+  // one transcendental: 1/(|a| + 1e-16) == 1/|a| in fp32 as soon as |a| > 1e-8 (|a|^2 > 1e-16); the
+  // exact form runs only for the (practically empty) set of smaller values
+  const float x = fmaf(a.re, a.re, a.im * a.im);
+  float sc;
+  if (__builtin_expect(x > 1e-15f, 1)) {
+    sc = S * __builtin_amdgcn_rsqf(x);
+  } else {
+    sc = S * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(x) + 1e-16f);
+  }
+#else
   const float mag = __builtin_amdgcn_sqrtf(fmaf(a.re, a.re, a.im * a.im));
   const float sc = S * __builtin_amdgcn_rcpf(mag + 1e-16f);
+#endif
 #else
   const float mag = sqrtf(fmaf(a.re, a.re, a.im * a.im));
   const float sc = S / (mag + 1e-16f);

@@ -32,6 +32,9 @@ namespace rfx {
 #ifndef RFX_MIN_WAVES
 #define RFX_MIN_WAVES 4
 #endif
+#ifndef RFX_NO_PREFETCH_D
+#define RFX_PREFETCH_D 1  // next frame's new analysis sample is loaded across the synthesis barrier
+#endif
 #ifndef RFX_STREAM_AUX
 #define RFX_STREAM_AUX 2  // gfx950 'nt': |S| and the injected angles are read once per launch
 #endif
@@ -91,10 +94,13 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
     return x;
   };
   float d[10];
+  float d_next = 0.f;
   if (MODE != 0) {
 #pragma unroll
     for (int j = 1; j < 10; ++j) d[j] = load_d(t0 + j - 1 - kHalfHops);  // blocks of frame t0-1 shifted in below
+    d_next = load_d(t0 + 9 - kHalfHops);
   }
+  (void)d_next;
 
   auto emit = [&](int blk, float val) {
     if (blk < 0 || blk >= nblk || !t.active) return;  // blk is wave-uniform
@@ -123,7 +129,11 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
       float u[10];
 #pragma unroll
       for (int j = 0; j < 9; ++j) d[j] = d[j + 1];
+#ifdef RFX_PREFETCH_D
+      d[9] = d_next;
+#else
       d[9] = load_d(fr + 9 - kHalfHops);
+#endif
 #pragma unroll
       for (int j = 0; j < 10; ++j) u[j] = d[j] * ld1(win, npr4, (unsigned)j * (kHop * 4u));
 #ifdef RFX_ABL_NOFFT
@@ -173,7 +183,12 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #pragma unroll
     for (int j = 0; j < 10; ++j) y[j] = R[j].re + R[j + 10].im + R[20].re;
 #else
+#ifdef RFX_PREFETCH_D
+    // the next frame's new analysis sample goes in flight across the synthesis barrier
+    frame_inverse(R, y, f, t, [&] { RFX_STAMP(4); if (MODE != 0) d_next = load_d(fr + 10 - kHalfHops); }, [&] { RFX_STAMP(5); });
+#else
     frame_inverse(R, y, f, t, [&] { RFX_STAMP(4); }, [&] { RFX_STAMP(5); });
+#endif
 #endif
 #pragma unroll
     for (int j = 0; j < 10; ++j) acc[j] = fmaf(y[j], ld1(win, npr4, (unsigned)j * (kHop * 4u)), acc[j]);

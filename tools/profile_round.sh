@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
 python - <<PY
 import csv, glob, json, collections
 out = "$OUT"
@@ -22,6 +23,7 @@ def agg(pattern, counter):
     return {k: (n, v / n) for k, (n, v) in tot.items()}
 fetch = agg(out + "/pmc_fetch/*counter_collection.csv", "FETCH_SIZE")
 write = agg(out + "/pmc_write/*counter_collection.csv", "WRITE_SIZE")
+sq = {c: agg(out + "/pmc_sq/*counter_collection.csv", c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")}
 res = {}
 for k in fetch:
     if "gl_iter_kernel<2>" in k:
@@ -31,6 +33,8 @@ for k in fetch:
         res = {"kernel": k, "launches_sampled": fetch[k][0], "FETCH_SIZE_kb_raw": f_kb, "WRITE_SIZE_kb_raw": w_kb,
                "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0,
                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE uncorrected"}
+        for c, table in sq.items():
+            if k in table: res[c + "_per_launch"] = table[k][1]
 json.dump(res, open(out + "/gl_iter_pmc.json", "w"), indent=1)
 print(json.dumps(res))
 PY
