@@ -101,7 +101,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = "RANK" in os.environ  # launched by torch.distributed.run (also exercised with one rank)
     if distributed:
         import torch.distributed as dist
 

@@ -191,7 +191,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     // group formulation (fast kernel): active bins contiguous with no zero row inside, first-filter index
     // non-decreasing, and the per-thread pairing (short group t, long group M-1-t) fits 8 + 24 registers
     std::vector<int> grp_start(M + 1, 0);
-    bool fast = ok && M <= 512;
+    bool fast = ok && M <= 512, perwave = false;
     if (fast) {
       int prev = 0;
       for (int f = f_lo; f < f_hi && fast; ++f) {
@@ -209,6 +209,14 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
           if (gH >= 0 && cnt[gH] > 24) fast = false;
           if (gL >= 0 && cnt[gL] > 8) fast = false;
           if (gL >= 0 && gH >= 0 && gL >= gH) fast = false;
+        }
+        // per-wave register budgets of imel_group_kernel_perwave<2,24, 4,16, 6,12, 6,10>
+        static const int lo_cap[4] = {2, 4, 6, 6}, hi_cap[4] = {24, 16, 12, 10};
+        perwave = fast;
+        for (int t2 = 0; t2 < 256 && perwave; ++t2) {
+          const int gH = M - 1 - t2, gL = t2 < M - 256 ? t2 : -1;
+          if (gH >= 0 && cnt[gH] > hi_cap[t2 >> 6]) perwave = false;
+          if (gL >= 0 && cnt[gL] > lo_cap[t2 >> 6]) perwave = false;
         }
       }
     }
@@ -244,7 +252,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       pl->imel.bin_pos = (const int*)(d + o_p);
       pl->imel.bin_pos2 = (const int*)(d + o_p2);
       pl->imel.grp_start = (const int*)(d + o_gs);
-      pl->imel.fast_ok = fast ? 1 : 0;
+      pl->imel.fast_ok = fast ? (perwave ? 2 : 1) : 0;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;

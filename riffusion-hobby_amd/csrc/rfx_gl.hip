@@ -102,13 +102,25 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   }
   (void)d_next;
 
-  auto emit = [&](int blk, float val) {
+  // a finished hop block: value * istft normalisation -> this run's parity buffer (and an explicit zero
+  // in the other one when no neighbouring run contributes to the block)
+  auto emit_scaled = [&](int blk, float scaled) {
     if (blk < 0 || blk >= nblk || !t.active) return;  // blk is wave-uniform
     const unsigned boff = (unsigned)blk * (kHop * 4u);
     const bool full = (max(blk - 4, 0) >= t0) && (min(blk + 5, g.T - 1) <= t1);
-    st1(val * ld1(scl, npr4, boff), outA, npr4, boff);
+    st1(scaled, outA, npr4, boff);
     if (full) st1(0.f, outB, npr4, boff);
   };
+  auto scale_of = [&](int blk) {
+    return (blk >= 0 && blk < nblk) ? ld1(scl, npr4, (unsigned)blk * (kHop * 4u)) : 0.f;
+  };
+  auto emit = [&](int blk, float val) { emit_scaled(blk, val * scale_of(blk)); };
+  // gfx950 retires VMEM loads and stores in issue order: a store issued at the end of a frame would sit
+  // in front of the next frame's first loads and expose its write latency.  The finished block is
+  // therefore parked in a register and stored after the next frame's analysis barrier, where a long
+  // LDS/VALU stretch follows; its normalisation factor is fetched across the synthesis barrier.
+  float pend_val = 0.f, pend_scale = 0.f;
+  int pend_blk = -1;
   __syncthreads();  // tw2 table in LDS
 
 #ifdef RFX_TIMING
@@ -141,7 +153,14 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #pragma unroll
       for (int kb = 0; kb < 21; ++kb) R[kb] = cf{u[kb % 10], u[(kb + 3) % 10]};
 #else
-      frame_forward(u, R, f, t, [&] { RFX_STAMP(1); mag_issue(mag, Ssrc, foff, q16); }, [&] { RFX_STAMP(0); });
+      frame_forward(u, R, f, t,
+                    [&] {
+                      RFX_STAMP(1);
+                      emit_scaled(pend_blk, pend_val);
+                      pend_blk = -1;
+                      mag_issue(mag, Ssrc, foff, q16);
+                    },
+                    [&] { RFX_STAMP(0); });
       RFX_STAMP(2);
 #endif
       // ---- angles = a / (|a| + 1e-16);  next spectrum estimate Z = |S| * angles
@@ -185,14 +204,29 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #else
 #ifdef RFX_PREFETCH_D
     // the next frame's new analysis sample goes in flight across the synthesis barrier
-    frame_inverse(R, y, f, t, [&] { RFX_STAMP(4); if (MODE != 0) d_next = load_d(fr + 10 - kHalfHops); }, [&] { RFX_STAMP(5); });
+    frame_inverse(R, y, f, t,
+                  [&] {
+                    RFX_STAMP(4);
+                    if (MODE != 0) d_next = load_d(fr + 10 - kHalfHops);
+                    pend_scale = scale_of(fr - kHalfHops);
+                  },
+                  [&] { RFX_STAMP(5); });
 #else
     frame_inverse(R, y, f, t, [&] { RFX_STAMP(4); }, [&] { RFX_STAMP(5); });
 #endif
 #endif
 #pragma unroll
     for (int j = 0; j < 10; ++j) acc[j] = fmaf(y[j], ld1(win, npr4, (unsigned)j * (kHop * 4u)), acc[j]);
+#ifdef RFX_PREFETCH_D
+    if (MODE != 0) {
+      pend_val = acc[0] * pend_scale;
+      pend_blk = fr - kHalfHops;
+    } else {
+      emit(fr - kHalfHops, acc[0]);
+    }
+#else
     emit(fr - kHalfHops, acc[0]);
+#endif
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = acc[j + 1];
     acc[9] = 0.f;
@@ -207,7 +241,8 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
     for (int i = 0; i < 8; ++i) g.timing[((size_t)blockIdx.x * 7 + w) * 8 + i] = tacc[i];
   }
 #endif
-  // ---- flush the right halo of the run
+  // ---- flush the parked block and the right halo of the run
+  emit_scaled(pend_blk, pend_val);
 #pragma unroll
   for (int j = 0; j < 9; ++j) emit(t1 - 4 + j, acc[j]);
 }

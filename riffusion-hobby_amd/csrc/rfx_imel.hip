@@ -253,8 +253,7 @@ __device__ __forceinline__ void group_store(const GroupState<N>& g, const ImelTa
 }
 
 template <int NLO, int NHI>
-__global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem) {
   const ImelTables& tb = a.tb;
   const int M = a.M;
   float* Ab = reinterpret_cast<float*>(smem);  // [2][M + 2], entry m at index m + 1
@@ -330,6 +329,26 @@ __global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
     for (int i = tid; i < a.max_iter; i += kImelThreads) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? hist_s[i] : 0.f;
 }
 
+// uniform register budget for every wave
+template <int NLO, int NHI>
+__global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  imel_group_body<NLO, NHI>(a, smem);
+}
+// group sizes fall with the wave index (mel spacing is logarithmic): each wave runs the body compiled for
+// its own maximum, so the long-group wave no longer sets everybody's instruction count.  All four bodies
+// execute the same sequence of barriers.
+template <int L0, int H0, int L1, int H1, int L2, int H2, int L3, int H3>
+__global__ void __launch_bounds__(kImelThreads) imel_group_kernel_perwave(ImelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: imel_group_body<L0, H0>(a, smem); break;
+    case 1: imel_group_body<L1, H1>(a, smem); break;
+    case 2: imel_group_body<L2, H2>(a, smem); break;
+    default: imel_group_body<L3, H3>(a, smem); break;
+  }
+}
+
 // one thread per clip: replays the reference's stopping rule on the clip-mean loss
 __global__ void imel_scan_kernel(const float* __restrict__ loss_hist, int* __restrict__ it_stop, int* __restrict__ any_early,
                                  int nclips, int C, int T, int max_iter, float tol_loss, float tol_change) {
@@ -362,7 +381,10 @@ __global__ void imel_scan_kernel(const float* __restrict__ loss_hist, int* __res
 hipError_t launch_imel(const ImelArgs& a, hipStream_t stream) {
   if (a.tb.fast_ok && !getenv("RFX_IMEL_GENERAL")) {
     const size_t lds = sizeof(float) * (4 * (a.M + 2) + 8 + a.max_iter);
-    hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
+    if (a.tb.fast_ok >= 2 && !getenv("RFX_IMEL_UNIFORM"))
+      hipLaunchKernelGGL((imel_group_kernel_perwave<2, 24, 4, 16, 6, 12, 6, 10>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
+    else
+      hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
     return hipGetLastError();
   }
   const int nb = a.tb.f_hi - a.tb.f_lo;

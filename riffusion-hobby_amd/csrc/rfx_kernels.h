@@ -69,7 +69,7 @@ struct ImelTables {
   const int* grp_start;  // [M+1] first bin of group g (bins whose first filter is g), fast path only
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
   int nnz;
-  int fast_ok;           // group formulation applicable with <8, 24> bins per thread
+  int fast_ok;           // 0: general kernel; 1: group formulation with <8, 24> bins per thread; 2: per-wave budgets fit too
 };
 struct ImelArgs {
   ImelTables tb;
