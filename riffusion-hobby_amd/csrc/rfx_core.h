@@ -184,77 +184,62 @@ RFX_HD void dft21(cf (&x)[21]) {
    0.70710678118654752440f, 0.80901699437494742410f, 0.89100652418836786236f, 0.95105651629515357212f,       \
    0.98768834059513772619f, 1.0f}
 
+// full 40th-root tables: cos / sin of 2*pi*i/40, i = 0..39
+#define RFX_C40F_TABLE {1.00000000000000000000f, 0.98768834059513777035f, 0.95105651629515353118f, 0.89100652418836789881f, 0.80901699437494745126f, 0.70710678118654757274f, 0.58778525229247313710f, 0.45399049973954680448f, 0.30901699437494745126f, 0.15643446504023092447f, 0.00000000000000006123f, -0.15643446504023059140f, -0.30901699437494734024f, -0.45399049973954669346f, -0.58778525229247302608f, -0.70710678118654746172f, -0.80901699437494734024f, -0.89100652418836778779f, -0.95105651629515353118f, -0.98768834059513765933f, -1.00000000000000000000f, -0.98768834059513777035f, -0.95105651629515375323f, -0.89100652418836789881f, -0.80901699437494756229f, -0.70710678118654768376f, -0.58778525229247324813f, -0.45399049973954691550f, -0.30901699437494756229f, -0.15643446504023103549f, -0.00000000000000018370f, 0.15643446504023067467f, 0.30901699437494722922f, 0.45399049973954663795f, 0.58778525229247291506f, 0.70710678118654735069f, 0.80901699437494734024f, 0.89100652418836778779f, 0.95105651629515353118f, 0.98768834059513765933f}
+#define RFX_S40F_TABLE {0.00000000000000000000f, 0.15643446504023086896f, 0.30901699437494739575f, 0.45399049973954674897f, 0.58778525229247313710f, 0.70710678118654746172f, 0.80901699437494745126f, 0.89100652418836778779f, 0.95105651629515353118f, 0.98768834059513777035f, 1.00000000000000000000f, 0.98768834059513777035f, 0.95105651629515364220f, 0.89100652418836789881f, 0.80901699437494745126f, 0.70710678118654757274f, 0.58778525229247324813f, 0.45399049973954685999f, 0.30901699437494750677f, 0.15643446504023097998f, 0.00000000000000012246f, -0.15643446504023073018f, -0.30901699437494689615f, -0.45399049973954669346f, -0.58778525229247302608f, -0.70710678118654746172f, -0.80901699437494734024f, -0.89100652418836778779f, -0.95105651629515353118f, -0.98768834059513765933f, -1.00000000000000000000f, -0.98768834059513777035f, -0.95105651629515364220f, -0.89100652418836800983f, -0.80901699437494756229f, -0.70710678118654768376f, -0.58778525229247335915f, -0.45399049973954697101f, -0.30901699437494761780f, -0.15643446504023111876f}
+
 // P1 forward: v[k1] = sum_{j=0..9} u[j] * w40^{j*k1}, k1 = 0..20, w40 = exp(-2*pi*i/40), u real.
-// Even/odd split j = 2p+s:  v[k] = E[k] + w40^k O[k],  v[20-k] = conj(E[k] - w40^k O[k]).
+// Even/odd split j = 2p+s:  v[k] = E[k] + O[k],  v[20-k] = conj(E[k] - O[k])  with
+//   E[k] = sum_p u[2p] w20^{pk},   O[k] = sum_p u[2p+1] w40^{(2p+1)k}   (k = 0..10).
 RFX_HD void p1_forward(const float (&u)[10], cf (&v)[21]) {
   constexpr float C20[20] = RFX_C20_TABLE;
   constexpr float S20[20] = RFX_S20_TABLE;
-  constexpr float C40[11] = RFX_C40_TABLE;
-  constexpr float S40[11] = RFX_S40_TABLE;
+  constexpr float C40[40] = RFX_C40F_TABLE;
+  constexpr float S40[40] = RFX_S40F_TABLE;
 #pragma unroll
   for (int k = 0; k <= 10; ++k) {
-    float er = u[0], ei = 0.f, orr = u[1], oi = 0.f;
+    float er = u[0], ei = 0.f;
+    float orr = C40[k % 40] * u[1], oi = -S40[k % 40] * u[1];
 #pragma unroll
     for (int p = 1; p < 5; ++p) {
-      const float c = C20[(p * k) % 20], s = S20[(p * k) % 20];
-      er = fmaf(c, u[2 * p], er);
-      ei = fmaf(-s, u[2 * p], ei);
-      orr = fmaf(c, u[2 * p + 1], orr);
-      oi = fmaf(-s, u[2 * p + 1], oi);
+      er = fmaf(C20[(p * k) % 20], u[2 * p], er);
+      ei = fmaf(-S20[(p * k) % 20], u[2 * p], ei);
+      orr = fmaf(C40[((2 * p + 1) * k) % 40], u[2 * p + 1], orr);
+      oi = fmaf(-S40[((2 * p + 1) * k) % 40], u[2 * p + 1], oi);
     }
-    // P = w40^k * O = (c - i s)(or + i oi)
-    const float c = C40[k], s = S40[k];
-    const float pr = fmaf(c, orr, s * oi), pi = fmaf(c, oi, -s * orr);
-    v[k] = cf{er + pr, ei + pi};
-    if (k < 10) v[20 - k] = cf{er - pr, -(ei - pi)};
+    v[k] = cf{er + orr, ei + oi};
+    if (k < 10) v[20 - k] = cf{er - orr, -(ei - oi)};
   }
 }
 
 // P1 inverse: y[j] = 0.5*(V0.re + (-1)^j V20.re) + sum_{k=1..19} Re(V[k] w40^{-k j}),  j = 0..9
-// (the caller folds the factor 2/N and the synthesis window into one multiplier).
+// (the caller folds the factor 2/N and the synthesis window into one multiplier).  Rows k and 20-k pair
+// up:  w40^{-(20-k) j} = (-1)^j conj(w40^{-k j}),  so with  B[k] = V[k] + conj(V[20-k])  (even j) and
+// D[k] = V[k] - conj(V[20-k])  (odd j)  each output is nine complex-times-constant real parts.
 RFX_HD void p1_inverse(const cf (&V)[21], float (&y)[10]) {
-  constexpr float C20[20] = RFX_C20_TABLE;
-  constexpr float S20[20] = RFX_S20_TABLE;
-  constexpr float C40[11] = RFX_C40_TABLE;
-  constexpr float S40[11] = RFX_S40_TABLE;
+  constexpr float C40[40] = RFX_C40F_TABLE;
+  constexpr float S40[40] = RFX_S40F_TABLE;
+  cf B[10], D[10];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    // A[k] = V[k] * w40^{-k s};  B[k] = A[k] + conj(A[20-k]), k = 1..9
-    cf B[10];
-    float a0, a10, a20;
-    if (s == 0) {
-      a0 = V[0].re;
-      a10 = V[10].re;
-      a20 = V[20].re;
+  for (int k = 1; k < 10; ++k) {
+    B[k] = cf{V[k].re + V[20 - k].re, V[k].im - V[20 - k].im};
+    D[k] = cf{V[k].re - V[20 - k].re, V[k].im + V[20 - k].im};
+  }
+  const float he = 0.5f * (V[0].re + V[20].re), ho = 0.5f * (V[0].re - V[20].re);
 #pragma unroll
-      for (int k = 1; k < 10; ++k) B[k] = cf{V[k].re + V[20 - k].re, V[k].im - V[20 - k].im};
-    } else {
-      a0 = V[0].re;
-      a10 = -V[10].im;  // w40^{-10} = exp(+i*pi/2) = i  ->  Re(i*V10) = -Im(V10)
-      a20 = -V[20].re;  // w40^{-20} = -1
+  for (int j = 0; j < 10; ++j) {
+    // k = 10 term: Re(V10 * w40^{-10 j}) = V10.re cos(pi j/2) - V10.im sin(pi j/2)
+    float acc = (j & 1) ? ho : he;
+    acc = fmaf(C40[(10 * j) % 40], V[10].re, acc);
+    acc = fmaf(-S40[(10 * j) % 40], V[10].im, acc);
 #pragma unroll
-      for (int k = 1; k < 10; ++k) {
-        // w40^{-k} = C40[k] + i S40[k];  w40^{-(20-k)} = -conj(w40^{-k})... computed directly:
-        const float c = C40[k], sn = S40[k];
-        // A[k] = V[k] * (c + i sn)
-        const float ar = fmaf(c, V[k].re, -sn * V[k].im), ai = fmaf(c, V[k].im, sn * V[k].re);
-        // A[20-k] = V[20-k] * w40^{-(20-k)} = V[20-k] * (-(c - i sn)) = V[20-k] * (-c + i sn)
-        const float br = fmaf(-c, V[20 - k].re, -sn * V[20 - k].im), bi = fmaf(-c, V[20 - k].im, sn * V[20 - k].re);
-        B[k] = cf{ar + br, ai - bi};
-      }
+    for (int k = 1; k < 10; ++k) {
+      const cf z = (j & 1) ? D[k] : B[k];
+      // Re(z * w40^{-k j}) = z.re cos(2 pi k j/40) - z.im sin(2 pi k j/40)
+      acc = fmaf(C40[(k * j) % 40], z.re, acc);
+      acc = fmaf(-S40[(k * j) % 40], z.im, acc);
     }
-    const float h = 0.5f * (a0 + a20);
-#pragma unroll
-    for (int p = 0; p < 5; ++p) {
-      float acc = (p & 1) ? h - a10 : h + a10;
-#pragma unroll
-      for (int k = 1; k < 10; ++k) {
-        // Re(B[k] * w20^{-k p}) = B.re cos(2 pi k p/20) - B.im sin(2 pi k p/20)
-        acc = fmaf(C20[(k * p) % 20], B[k].re, acc);
-        acc = fmaf(-S20[(k * p) % 20], B[k].im, acc);
-      }
-      y[2 * p + s] = acc;
-    }
+    y[j] = acc;
   }
 }
 
