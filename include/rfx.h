@@ -104,6 +104,12 @@ size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw);
 int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Standalone torchaudio.transforms.MelScale.forward (spectrogram_converter.py:185) for callers that hold linear
+ * magnitudes in the reference's (B, n_stft, T) layout: packs them into slots and runs the same MFMA projection.
+ * Workspace: rfx_frame_stride() * B * T floats. */
+int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_mel_out, void* d_workspace,
+                  size_t workspace_bytes, void* stream);
+
 /* ---- inverse: torchaudio.transforms.InverseMelScale (SGD, max_iter = params.max_mel_iters,
  * tolerance_loss 1e-5, tolerance_change 1e-8, lr 0.1, momentum 0.9), spectrogram_converter.py:87-99,
  * called at :201.  d_mel (B, n_mels, T); the B rows are grouped into clips of `channels_per_clip`

@@ -75,6 +75,8 @@ int rfx_version(void) { return 1; }
 int rfx_frame_stride(void) { return kFrameStride; }
 int rfx_num_bins(void) { return kBins; }
 
+int rfx_plan_destroy(rfx_plan* plan);
+
 int rfx_plan_create(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
                     rfx_plan** out_plan) {
   if (!params || !out_plan || !h_window) return fail(RFX_ERR_INVALID, "rfx_plan_create: null argument");
@@ -83,6 +85,10 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
                 "rfx_plan_create: only the 44.1 kHz geometry n_fft=17640 win=4410 hop=441 is implemented in HIP");
   RFX_HIP(hipSetDevice(device));
   rfx_plan* pl = new rfx_plan();
+  struct Guard {  // releases the half-built plan if any step below fails
+    rfx_plan* p;
+    ~Guard() { if (p) rfx_plan_destroy(p); }
+  } guard{pl};
   pl->p = *params;
   pl->device = device;
   pl->n_stft = params->n_fft / 2 + 1;
@@ -258,6 +264,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       pl->imel.nnz = (int)nnz;
     }
   }
+  guard.p = nullptr;
   *out_plan = pl;
   return RFX_OK;
 }
@@ -466,6 +473,26 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
   a.M = plan->p.n_mels;
   a.T = 1 + Lw / kHop;
   a.N = B * a.T;
+  RFX_HIP(launch_mel_gemm(a, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_mel_out, void* d_workspace,
+                  size_t workspace_bytes, void* stream) {
+  if (!plan || !d_lin_bft || !d_mel_out || !d_workspace || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_mel_scale: bad argument");
+  if (!plan->d_melfb_slots) return fail(RFX_ERR_INVALID, "rfx_mel_scale: plan was created without a mel filterbank");
+  if (workspace_bytes < align_up((size_t)B * T * kFrameStride * sizeof(float), 256)) return fail(RFX_ERR_WORKSPACE, "rfx_mel_scale: workspace too small");
+  float* mag = (float*)d_workspace;
+  RFX_HIP(launch_pack_mag(d_lin_bft, mag, B, T, (hipStream_t)stream));
+  MelArgs a;
+  a.mag = mag;
+  a.fbs = plan->d_melfb_slots;
+  a.kblocks = plan->d_kblocks;
+  a.n_kblocks = plan->n_kblocks;
+  a.out = d_mel_out;
+  a.M = plan->p.n_mels;
+  a.T = T;
+  a.N = B * T;
   RFX_HIP(launch_mel_gemm(a, (hipStream_t)stream));
   return RFX_OK;
 }

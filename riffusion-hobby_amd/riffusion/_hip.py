@@ -72,6 +72,7 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_unpack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rfx_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_mel_from_waveform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rfx_mel_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rfx_inverse_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_inverse_mel": (
         c_int,
@@ -335,6 +336,17 @@ class Plan:
                 self.handle, wave.data_ptr(), B, Lw, out.data_ptr(), ws.data_ptr(), ws.numel(), current_stream()
             )
         )
+        return out
+
+    def mel_scale(self, lin_bft: torch.Tensor) -> torch.Tensor:
+        """MelScale.forward on (B, n_stft, T) magnitudes through the MFMA projection."""
+        lin_bft = self._chk(lin_bft, torch.float32)
+        B, F, Tn = lin_bft.shape
+        if F != self.n_stft:
+            raise ValueError(f"expected {self.n_stft} linear bins, got {F}")
+        ws = torch.empty(B * Tn * self.frame_stride * 4 + 256, dtype=torch.uint8, device=lin_bft.device)
+        out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=lin_bft.device)
+        check(self.lib.rfx_mel_scale(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), ws.data_ptr(), ws.numel(), current_stream()))
         return out
 
     def inverse_mel(

@@ -87,10 +87,9 @@ class SpectrogramConverter:
     def _mel_scale(self, amplitudes: torch.Tensor) -> torch.Tensor:
         """(B, n_stft, T) -> (B, n_mels, T); standalone use only (the fused path never builds the input)."""
         plan = self._plan()
-        fb = plan.melfb.to(amplitudes.device)
-        # A plain library GEMM: this member is not on the hot path (mel_amplitudes_from_waveform fuses
-        # STFT magnitude and projection in HIP); kept for API compatibility.
-        return torch.matmul(amplitudes.transpose(-1, -2), fb).transpose(-1, -2)
+        lead = amplitudes.shape[:-2]
+        x = amplitudes.reshape(-1, amplitudes.shape[-2], amplitudes.shape[-1]).to(self.device)
+        return plan.mel_scale(x).reshape(*lead, plan.n_mels, x.shape[-1])
 
     def _inverse_mel_scale(
         self, melspec: torch.Tensor, *, spec0: T.Optional[torch.Tensor] = None, seed: T.Optional[int] = None

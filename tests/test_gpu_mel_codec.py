@@ -209,6 +209,12 @@ def test_converter_round_trip_api(params, O):
     assert lin.shape == (1, op.n_stft, T)
     spec = conv.spectrogram_func(got)
     assert spec.shape == (1, op.n_stft, T) and spec.dtype == torch.complex64
+    # the four members chain exactly like the reference's forward path (:179-185)
+    mel2 = conv.mel_scaler(torch.abs(spec))
+    fused = conv.mel_amplitudes_from_waveform(got)
+    assert mel2.shape == fused.shape and torch.linalg.norm(mel2 - fused) / torch.linalg.norm(fused) < 1e-5
+    ref_mel = O.mel_scale(torch.abs(spec).cpu(), O.mel_filterbank(op))
+    assert torch.linalg.norm(mel2.cpu() - ref_mel) / torch.linalg.norm(ref_mel) < 1e-5
 
 
 def test_image_converter_batch_and_single(params, golden_dir):
