@@ -264,3 +264,28 @@ def test_stereo_tiles_64_iterations_end_to_end(O):
     ref = O.waveform_from_mel_amplitudes(mel, op, spec0=spec0, angles0=angles0)
     got = conv.waveform_from_mel_amplitudes(mel, spec0=spec0, angles0=angles0).cpu()
     assert snr_db(ref, got) >= 40.0  # >= 40 dB at 64 iterations
+
+
+@pytest.mark.parametrize("kw", [dict(min_frequency=20, max_frequency=20000), dict(num_frequencies=256)])
+def test_inverse_mel_other_parameter_sets_use_fallback_kernels(O, kw):
+    """Mel parameters outside the fast kernel's register budget run the general banded kernel."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    p = SpectrogramParams(max_mel_iters=60, **kw)
+    op = O.params_from(p)
+    plan = _hip.get_plan(p, "cuda")
+    T, C = 6, 1
+    g = torch.Generator().manual_seed(17)
+    mel = torch.rand(C, p.num_frequencies, T, generator=g) ** 3 * 2e7
+    spec0 = torch.rand(C, T, op.n_stft, generator=g)
+    ref = O.inverse_mel_scale_sgd(mel, op, spec0=spec0)
+    got = plan.unpack_magnitudes(plan.inverse_mel(mel.cuda(), C, spec0=spec0.cuda()), C, T).cpu()
+    active = O.mel_filterbank(op).abs().sum(1) > 0
+    assert torch.linalg.norm(got[:, active] - ref[:, active]) / torch.linalg.norm(ref[:, active]) <= 1e-3
+    assert torch.equal(got[:, ~active], spec0.transpose(1, 2)[:, ~active])
+    # and the forward projection with the same parameters
+    wave = synthetic_wave(1, 441 * 40, seed=2)
+    fwd = plan.mel_from_waveform(wave.cuda()).cpu()
+    fref = O.mel_amplitudes_from_waveform(wave, op)
+    assert torch.linalg.norm(fwd - fref) / torch.linalg.norm(fref) <= 1e-4
