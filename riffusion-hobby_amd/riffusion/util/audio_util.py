@@ -69,6 +69,38 @@ class PcmSegment:
             return PcmSegment(np.clip(left + right, -32768, 32767).astype(np.int16), self.frame_rate)
         raise ValueError("PcmSegment.set_channels only converts between mono and stereo")
 
+    # ---- the gain filters audio_util.apply_filters needs, restated from pydub 0.25 (AudioSegment.rms / dBFS /
+    # max / apply_gain, effects.normalize) and CPython's audioop (rms = floor(sqrt(mean square)), mul =
+    # floor of the clipped product).  pydub is not installed here: these are UNPINNED restatements.
+    max_possible_amplitude = 32768.0
+
+    @property
+    def rms(self) -> int:
+        x = self._data.astype(np.float64).reshape(-1)
+        return int(np.sqrt(np.sum(x * x) / x.size)) if x.size else 0
+
+    @property
+    def dBFS(self) -> float:
+        rms = self.rms
+        return float("-inf") if rms == 0 else 20.0 * float(np.log10(rms / self.max_possible_amplitude))
+
+    @property
+    def max(self) -> int:
+        return int(np.abs(self._data.astype(np.int32)).max()) if self._data.size else 0
+
+    def apply_gain(self, volume_change: float) -> "PcmSegment":
+        factor = 10.0 ** (float(volume_change) / 20.0)
+        v = self._data.astype(np.float64) * factor
+        v = np.where(v > 32767.0, 32767.0, np.where(v < -32767.0, -32768.0, v))  # audioop's fbound
+        return PcmSegment(np.floor(v).astype(np.int16), self.frame_rate)
+
+    def normalize(self, headroom: float = 0.1) -> "PcmSegment":
+        peak = self.max
+        if peak == 0:
+            return self
+        target_peak = self.max_possible_amplitude * 10.0 ** (-headroom / 20.0)
+        return self.apply_gain(20.0 * float(np.log10(target_peak / peak)))
+
     def export(self, out_f: T.Any, format: str = "wav") -> T.Any:
         if format != "wav":
             raise NotImplementedError("PcmSegment exports wav only; install pydub + ffmpeg for other formats")
@@ -118,14 +150,16 @@ def audio_from_waveform(samples: np.ndarray, sample_rate: int, normalize: bool =
 
 
 def apply_filters(segment: T.Any, compression: bool = False) -> T.Any:
-    """Gain to -12 dBFS and peak normalisation with 0.1 dB headroom (reference audio_util.py:39-72).
-    These are pydub / audioop integer filters on the host; they need pydub."""
+    """Gain to -12 dBFS and peak normalisation with 0.1 dB headroom (reference audio_util.py:39-72): pydub /
+    audioop integer filters on the host.  pydub segments go through pydub itself; PcmSegment carries a
+    restatement of the two filters."""
+    if isinstance(segment, PcmSegment):
+        if compression:
+            raise NotImplementedError("dynamic range compression needs pydub (the hot path calls compression=False)")
+        return segment.apply_gain(-12 - segment.dBFS).normalize(headroom=0.1)
     pydub = _pydub()
-    if pydub is None or isinstance(segment, PcmSegment):
-        raise NotImplementedError(
-            "apply_filters uses pydub's gain/normalize filters; pydub is not installed - "
-            "call with apply_filters=False or install pydub"
-        )
+    if pydub is None:
+        raise NotImplementedError("apply_filters on a foreign segment type needs pydub")
     if compression:
         segment = pydub.effects.normalize(segment, headroom=0.1)
         segment = segment.apply_gain(-10 - segment.dBFS)

@@ -114,3 +114,36 @@ def test_forward_batch_equals_per_clip(params):
     full = plan.mel_from_waveform(wave)
     for i in range(5):
         assert torch.equal(full[i : i + 1], plan.mel_from_waveform(wave[i : i + 1]))
+
+
+def test_cli_round_trips_like_the_reference_tests(golden_dir, tmp_path):
+    """reference test/image_to_audio_test.py:40-67 and test/audio_to_image_test.py:57-99 through our CLI."""
+    import os
+
+    from PIL import Image
+
+    from riffusion import cli
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import audio_util
+
+    png = os.path.join(golden_dir, "clip_2_start_103694_ms_duration_5678_ms_stereo.png")
+    wav_out = str(tmp_path / "out.wav")
+    cli.main(["image-to-audio", "--image", png, "--audio", wav_out, "--device", "cuda"])
+    seg = audio_util.PcmSegment.from_wav(wav_out)
+    assert seg.frame_rate == 44100 and seg.channels == 2
+    assert abs(seg.duration_seconds - 5.678) < 0.010 + 1.0 / 100  # duration within one hop of the clip (reference: 10 ms)
+    png_out = str(tmp_path / "out.png")
+    cli.main(["audio-to-image", "--audio", os.path.join(golden_dir, "clip_2_start_103694_ms_duration_5678_ms.wav"),
+              "--image", png_out, "--stereo"])
+    im = Image.open(png_out)
+    assert im.mode == "RGB" and im.size == (568, 512) and np.all(np.array(im)[..., 0] == 0)
+    assert SpectrogramParams.from_exif(im.getexif()) == SpectrogramParams(stereo=True)
+    gold = np.array(Image.open(png).convert("RGB"))
+    assert np.abs(np.array(im).astype(int) - gold.astype(int)).max() <= 1
+    # batch command: three copies of a tile decode in one GPU call
+    tiles = tmp_path / "tiles"
+    tiles.mkdir()
+    for i in range(3):
+        Image.open(os.path.join(golden_dir, "og_beat_64.png")).save(str(tiles / f"t{i}.png"))
+    cli.main(["images-to-audio-batch", "--image-dir", str(tiles), "--output-dir", str(tmp_path / "wavs")])
+    assert sorted(os.listdir(tmp_path / "wavs")) == ["t0.wav", "t1.wav", "t2.wav"]
