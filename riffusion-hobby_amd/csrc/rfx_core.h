@@ -250,11 +250,7 @@ RFX_HD int cube_at(int k1, int a, int b) { return (k1 * 21 + a) * 21 + b; }
 
 // Twiddles are passed as accessors `tw(i) -> cf` so that the kernels can stream them from a table
 // (L2 / LDS) exactly where they are consumed instead of pinning 42 registers per table, while the
-// host emulator indexes plain arrays.  RFX_SCHED_FENCE() marks the points the device compiler must
-// not schedule across (it bounds how many table loads are in flight, i.e. the register pressure).
-#ifndef RFX_SCHED_FENCE
-#define RFX_SCHED_FENCE() ((void)0)
-#endif
+// host emulator indexes plain arrays.
 
 // P1 store: thread n' = 21a+b twiddles its 21 outputs and scatters them to rows k1
 template <class TW>

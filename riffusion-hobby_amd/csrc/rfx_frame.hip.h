@@ -14,7 +14,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define RFX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #include "rfx_core.h"
 
 namespace rfx {
