@@ -111,3 +111,11 @@ def test_griffinlim_random_init_converges_like_oracle(plan, oparams):
     sc_ref = O.spectral_convergence(ref, mag, oparams)
     sc_got = O.spectral_convergence(got, mag, oparams)
     assert abs(sc_got - sc_ref) / sc_ref < 0.10, (sc_got, sc_ref)
+
+
+@pytest.mark.parametrize("B,T", [(1, 22), (1, 57), (2, 101), (3, 568), (7, 33), (5, 200), (1, 1024)])
+def test_griffinlim_shape_sweep(plan, oparams, B, T):
+    """Run partitioning / halo logic over awkward shapes: few frames per run, uneven runs, long clips."""
+    ref, got, _ = _gl_case(plan, oparams, B=B, T=T, n_iter=3, seed=1000 + 7 * B + T)
+    assert got.shape == ref.shape == (B, 441 * (T - 1))
+    assert snr_db(ref, got) >= 95.0
