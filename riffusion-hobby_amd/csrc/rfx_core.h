@@ -189,36 +189,64 @@ RFX_HD void dft21(cf (&x)[21]) {
 #define RFX_S40F_TABLE {0.00000000000000000000f, 0.15643446504023086896f, 0.30901699437494739575f, 0.45399049973954674897f, 0.58778525229247313710f, 0.70710678118654746172f, 0.80901699437494745126f, 0.89100652418836778779f, 0.95105651629515353118f, 0.98768834059513777035f, 1.00000000000000000000f, 0.98768834059513777035f, 0.95105651629515364220f, 0.89100652418836789881f, 0.80901699437494745126f, 0.70710678118654757274f, 0.58778525229247324813f, 0.45399049973954685999f, 0.30901699437494750677f, 0.15643446504023097998f, 0.00000000000000012246f, -0.15643446504023073018f, -0.30901699437494689615f, -0.45399049973954669346f, -0.58778525229247302608f, -0.70710678118654746172f, -0.80901699437494734024f, -0.89100652418836778779f, -0.95105651629515353118f, -0.98768834059513765933f, -1.00000000000000000000f, -0.98768834059513777035f, -0.95105651629515364220f, -0.89100652418836800983f, -0.80901699437494756229f, -0.70710678118654768376f, -0.58778525229247335915f, -0.45399049973954697101f, -0.30901699437494761780f, -0.15643446504023111876f}
 
 // P1 forward: v[k1] = sum_{j=0..9} u[j] * w40^{j*k1}, k1 = 0..20, w40 = exp(-2*pi*i/40), u real.
-// Even/odd split j = 2p+s:  v[k] = E[k] + O[k],  v[20-k] = conj(E[k] - O[k])  with
-//   E[k] = sum_p u[2p] w20^{pk},   O[k] = sum_p u[2p+1] w40^{(2p+1)k}   (k = 0..10).
+//   j = 2p+s:   E[k] = sum_p u[2p] w20^{pk},   O[k] = sum_p u[2p+1] w40^{(2p+1)k}
+//   v[k] = E[k] + O[k],   v[20-k] = conj(E[k] - O[k])                                  (u real)
+// and, splitting p into even / odd (Ee, Eo, Oe, Oo), the mirror k -> 10-k comes for free:
+//   E[10-k] = conj(Ee - Eo),   O[10-k] = -i * conj(Oe - Oo)
+// so only k = 1..4 need the trigonometric sums (k = 0, 5, 10 are sign patterns / eighth roots).
 RFX_HD void p1_forward(const float (&u)[10], cf (&v)[21]) {
-  constexpr float C20[20] = RFX_C20_TABLE;
-  constexpr float S20[20] = RFX_S20_TABLE;
   constexpr float C40[40] = RFX_C40F_TABLE;
   constexpr float S40[40] = RFX_S40F_TABLE;
+  constexpr float R = 0.70710678118654752440f;
+  const float e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], e4 = u[8];
+  const float o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7], o4 = u[9];
+  {  // k = 0 and k = 10
+    const float ee = e0 + e2 + e4, eo = e1 + e3, oe = o0 + o2 + o4, oo = o1 + o3;
+    const float E0 = ee + eo, O0 = oe + oo;
+    v[0] = cf{E0 + O0, 0.f};
+    v[20] = cf{E0 - O0, 0.f};
+    v[10] = cf{ee - eo, -(oe - oo)};  // E[10] = ee - eo (real), O[10] = -i (oe - oo)
+  }
+  {  // k = 5: w20^{5p} = (-i)^p, w40^{5(2p+1)} = w8^{2p+1}
+    const float Er = e0 - e2 + e4, Ei = e3 - e1;
+    const float Or = R * ((o0 + o3 + o4) - (o1 + o2)), Oi = R * ((o2 + o3) - (o0 + o1 + o4));
+    v[5] = cf{Er + Or, Ei + Oi};
+    v[15] = cf{Er - Or, -(Ei - Oi)};
+  }
 #pragma unroll
-  for (int k = 0; k <= 10; ++k) {
-    float er = u[0], ei = 0.f;
-    float orr = C40[k % 40] * u[1], oi = -S40[k % 40] * u[1];
-#pragma unroll
-    for (int p = 1; p < 5; ++p) {
-      er = fmaf(C20[(p * k) % 20], u[2 * p], er);
-      ei = fmaf(-S20[(p * k) % 20], u[2 * p], ei);
-      orr = fmaf(C40[((2 * p + 1) * k) % 40], u[2 * p + 1], orr);
-      oi = fmaf(-S40[((2 * p + 1) * k) % 40], u[2 * p + 1], oi);
-    }
-    v[k] = cf{er + orr, ei + oi};
-    if (k < 10) v[20 - k] = cf{er - orr, -(ei - oi)};
+  for (int k = 1; k <= 4; ++k) {
+    // w20^{pk} = w40^{2pk}; forward kernel exp(-i theta) = cos - i sin
+    const float eer = fmaf(C40[(8 * k) % 40], e4, fmaf(C40[(4 * k) % 40], e2, e0));
+    const float eei = -fmaf(S40[(8 * k) % 40], e4, S40[(4 * k) % 40] * e2);
+    const float eor = fmaf(C40[(6 * k) % 40], e3, C40[(2 * k) % 40] * e1);
+    const float eoi = -fmaf(S40[(6 * k) % 40], e3, S40[(2 * k) % 40] * e1);
+    const float oer = fmaf(C40[(9 * k) % 40], o4, fmaf(C40[(5 * k) % 40], o2, C40[k % 40] * o0));
+    const float oei = -fmaf(S40[(9 * k) % 40], o4, fmaf(S40[(5 * k) % 40], o2, S40[k % 40] * o0));
+    const float oor = fmaf(C40[(7 * k) % 40], o3, C40[(3 * k) % 40] * o1);
+    const float ooi = -fmaf(S40[(7 * k) % 40], o3, S40[(3 * k) % 40] * o1);
+    const float Er = eer + eor, Ei = eei + eoi, Or = oer + oor, Oi = oei + ooi;  // E[k], O[k]
+    v[k] = cf{Er + Or, Ei + Oi};
+    v[20 - k] = cf{Er - Or, -(Ei - Oi)};
+    // mirror 10-k:  E[10-k] = conj(Ee - Eo);  O[10-k] = -i conj(D), D = Oe - Oo:  -i (dr - i di) = -di - i dr
+    const float Fr = eer - eor, Fi = -(eei - eoi);
+    const float dr = oer - oor, di = oei - ooi;
+    const float Gr = -di, Gi = -dr;
+    v[10 - k] = cf{Fr + Gr, Fi + Gi};
+    v[10 + k] = cf{Fr - Gr, -(Fi - Gi)};
   }
 }
 
 // P1 inverse: y[j] = 0.5*(V0.re + (-1)^j V20.re) + sum_{k=1..19} Re(V[k] w40^{-k j}),  j = 0..9
-// (the caller folds the factor 2/N and the synthesis window into one multiplier).  Rows k and 20-k pair
-// up:  w40^{-(20-k) j} = (-1)^j conj(w40^{-k j}),  so with  B[k] = V[k] + conj(V[20-k])  (even j) and
-// D[k] = V[k] - conj(V[20-k])  (odd j)  each output is nine complex-times-constant real parts.
+// (the caller folds the factor 2/N and the synthesis window into one multiplier).
+// Rows k and 20-k pair up (w40^{-(20-k) j} = (-1)^j conj(w40^{-k j})):  B = V[k] + conj(V[20-k]) feeds the
+// even outputs, D = V[k] - conj(V[20-k]) the odd ones; then k and 10-k pair up once more:
+//   even j = 2p :  w40^{-(10-k) 2p} = (-1)^p conj(w40^{-2kp})        ->  B[k] +- conj(B[10-k])
+//   odd  j = 2p+1: w40^{-(10-k)(2p+1)} = i (-1)^p conj(w40^{-k(2p+1)}) ->  D[k] +- (-i) conj(D[10-k])
+// leaving four complex-times-constant real parts per output plus the k = 5 and k = 10 sign patterns.
 RFX_HD void p1_inverse(const cf (&V)[21], float (&y)[10]) {
   constexpr float C40[40] = RFX_C40F_TABLE;
   constexpr float S40[40] = RFX_S40F_TABLE;
+  constexpr float R = 0.70710678118654752440f;
   cf B[10], D[10];
 #pragma unroll
   for (int k = 1; k < 10; ++k) {
@@ -226,20 +254,54 @@ RFX_HD void p1_inverse(const cf (&V)[21], float (&y)[10]) {
     D[k] = cf{V[k].re - V[20 - k].re, V[k].im + V[20 - k].im};
   }
   const float he = 0.5f * (V[0].re + V[20].re), ho = 0.5f * (V[0].re - V[20].re);
+  // ---- even outputs j = 2p
+  {
+    cf G[5], H[5];  // G = B[k] + conj(B[10-k]) (p even), H = B[k] - conj(B[10-k]) (p odd)
 #pragma unroll
-  for (int j = 0; j < 10; ++j) {
-    // k = 10 term: Re(V10 * w40^{-10 j}) = V10.re cos(pi j/2) - V10.im sin(pi j/2)
-    float acc = (j & 1) ? ho : he;
-    acc = fmaf(C40[(10 * j) % 40], V[10].re, acc);
-    acc = fmaf(-S40[(10 * j) % 40], V[10].im, acc);
-#pragma unroll
-    for (int k = 1; k < 10; ++k) {
-      const cf z = (j & 1) ? D[k] : B[k];
-      // Re(z * w40^{-k j}) = z.re cos(2 pi k j/40) - z.im sin(2 pi k j/40)
-      acc = fmaf(C40[(k * j) % 40], z.re, acc);
-      acc = fmaf(-S40[(k * j) % 40], z.im, acc);
+    for (int k = 1; k <= 4; ++k) {
+      G[k] = cf{B[k].re + B[10 - k].re, B[k].im - B[10 - k].im};
+      H[k] = cf{B[k].re - B[10 - k].re, B[k].im + B[10 - k].im};
     }
-    y[j] = acc;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      // k = 10: Re(V10 w40^{-20p}) = (-1)^p V10.re ;  k = 5: Re(B5 w40^{-10p}) = Re(B5 i^p)
+      float acc = (p & 1) ? he - V[10].re : he + V[10].re;
+      acc += (p % 4 == 0) ? B[5].re : (p % 4 == 1) ? -B[5].im : (p % 4 == 2) ? -B[5].re : B[5].im;
+#pragma unroll
+      for (int k = 1; k <= 4; ++k) {
+        const cf z = (p & 1) ? H[k] : G[k];
+        acc = fmaf(C40[(2 * k * p) % 40], z.re, acc);
+        acc = fmaf(-S40[(2 * k * p) % 40], z.im, acc);
+      }
+      y[2 * p] = acc;
+    }
+  }
+  // ---- odd outputs j = 2p+1
+  {
+    cf G[5], H[5];  // G = D[k] + (-i) conj(D[10-k]) (p even), H = D[k] - (-i) conj(D[10-k]) (p odd)
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) {
+      // (-i) * conj(x + i y) = (-i)(x - i y) = -y - i x
+      const float qr = -D[10 - k].im, qi = -D[10 - k].re;
+      G[k] = cf{D[k].re + qr, D[k].im + qi};
+      H[k] = cf{D[k].re - qr, D[k].im - qi};
+    }
+    // k = 5: Re(D5 w40^{-5(2p+1)}) = Re(D5 w8^{-(2p+1)}),  w8^{-1} = R(1+i), w8^{-3} = R(-1+i), w8^{-5} = R(-1-i), w8^{-7} = R(1-i)
+    const float s5 = R * (D[5].re - D[5].im), t5 = R * (D[5].re + D[5].im);
+    // k = 10: Re(V10 w40^{-10(2p+1)}) = Re(V10 i^{2p+1}) = (-1)^{p+1} V10.im
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      float acc = (p & 1) ? ho + V[10].im : ho - V[10].im;
+      // Re(D5 R(a + i b)) = R(a D5.re - b D5.im):  p=0: (1,1)->s5 ; p=1: (-1,1)-> -t5 ; p=2: (-1,-1)-> -s5 ; p=3: (1,-1)-> t5 ; p=4: as p=0
+      acc += (p % 4 == 0) ? s5 : (p % 4 == 1) ? -t5 : (p % 4 == 2) ? -s5 : t5;
+#pragma unroll
+      for (int k = 1; k <= 4; ++k) {
+        const cf z = (p & 1) ? H[k] : G[k];
+        acc = fmaf(C40[(k * (2 * p + 1)) % 40], z.re, acc);
+        acc = fmaf(-S40[(k * (2 * p + 1)) % 40], z.im, acc);
+      }
+      y[2 * p + 1] = acc;
+    }
   }
 }
 
