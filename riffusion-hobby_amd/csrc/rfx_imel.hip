@@ -235,9 +235,13 @@ template <int N>
 __device__ __forceinline__ void group_step(GroupState<N>& g, float d0, float d1, bool first, float mom, float lr) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const float gr = fmaf(d0, g.w0[i], d1 * g.w1[i]);
-    g.buf[i] = first ? gr : fmaf(mom, g.buf[i], gr);
-    g.spec[i] = fmaxf(0.f, fmaf(-lr, g.buf[i], g.spec[i]));
+    // torch.optim.SGD: buf.mul_(momentum).add_(grad); accumulating in place keeps buf in its register
+    // (a separate gradient temporary costs a v_mov per bin and step across the loop back-edge)
+    float bnew = first ? 0.f : mom * g.buf[i];
+    bnew = fmaf(d0, g.w0[i], bnew);
+    bnew = fmaf(d1, g.w1[i], bnew);
+    g.buf[i] = bnew;
+    g.spec[i] = fmaxf(0.f, fmaf(-lr, bnew, g.spec[i]));
   }
 }
 template <int N>
@@ -339,7 +343,11 @@ __global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
 // its own maximum, so the long-group wave no longer sets everybody's instruction count.  All four bodies
 // execute the same sequence of barriers.
 template <int L0, int H0, int L1, int H1, int L2, int H2, int L3, int H3>
-__global__ void __launch_bounds__(kImelThreads) imel_group_kernel_perwave(ImelArgs a) {
+#ifndef RFX_IMEL_WAVES_PER_EU
+#define RFX_IMEL_WAVES_PER_EU 4  // 128 VGPRs: 4 workgroups per CU (7.6 ms vs 8.6 ms at 3, measured)
+#endif
+__global__ void __launch_bounds__(kImelThreads) __attribute__((amdgpu_waves_per_eu(RFX_IMEL_WAVES_PER_EU)))
+imel_group_kernel_perwave(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
     case 0: imel_group_body<L0, H0>(a, smem); break;
