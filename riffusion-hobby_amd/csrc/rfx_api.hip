@@ -216,8 +216,9 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
           if (gL >= 0 && cnt[gL] > 8) fast = false;
           if (gL >= 0 && gH >= 0 && gL >= gH) fast = false;
         }
-        // per-wave register budgets of imel_group_kernel_perwave<2,24, 4,16, 6,12, 6,10>
-        static const int lo_cap[4] = {2, 4, 6, 6}, hi_cap[4] = {24, 16, 12, 10};
+        // per-wave register budgets of imel_group_kernel_perwave (rfx_kernels.h)
+        const int* lo_cap = rfx::kImelLoCap;
+        const int* hi_cap = rfx::kImelHiCap;
         perwave = fast;
         for (int t2 = 0; t2 < 256 && perwave; ++t2) {
           const int gH = M - 1 - t2, gL = t2 < M - 256 ? t2 : -1;

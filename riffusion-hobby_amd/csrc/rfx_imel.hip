@@ -390,7 +390,8 @@ hipError_t launch_imel(const ImelArgs& a, hipStream_t stream) {
   if (a.tb.fast_ok && !getenv("RFX_IMEL_GENERAL")) {
     const size_t lds = sizeof(float) * (4 * (a.M + 2) + 8 + a.max_iter);
     if (a.tb.fast_ok >= 2 && !getenv("RFX_IMEL_UNIFORM"))
-      hipLaunchKernelGGL((imel_group_kernel_perwave<2, 24, 4, 16, 6, 12, 6, 10>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
+      hipLaunchKernelGGL((imel_group_kernel_perwave<kImelLoCap[0], kImelHiCap[0], kImelLoCap[1], kImelHiCap[1], kImelLoCap[2], kImelHiCap[2],
+                                                   kImelLoCap[3], kImelHiCap[3]>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
     else
       hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
     return hipGetLastError();

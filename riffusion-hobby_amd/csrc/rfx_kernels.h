@@ -56,6 +56,13 @@ struct MelArgs {
 };
 hipError_t launch_mel_gemm(const MelArgs& a, hipStream_t stream);
 
+// Per-wave register budgets (bins per thread) of the InverseMelScale fast path: wave w owns the short groups
+// 64w .. 64w+63 and the long groups M-1-64w .. M-64-64w.  Sized exactly to the reference's default bank
+// (0-10 kHz, 512 HTK filters over 8821 bins); plan creation falls back to the uniform kernel when a bank
+// does not fit.
+constexpr int kImelLoCap[4] = {2, 3, 5, 6};
+constexpr int kImelHiCap[4] = {23, 16, 12, 9};
+
 // banded InverseMelScale SGD (torchaudio 0.13 semantics), one workgroup per frame
 struct ImelTables {
   const float* csr_w;    // [nnz] filterbank weights, mel-major (column m = bins fs[m] .. fe[m]-1)
