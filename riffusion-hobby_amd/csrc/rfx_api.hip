@@ -42,6 +42,7 @@ struct rfx_plan {
   float* d_melfb = nullptr;        // [n_stft][n_mels] as given
   int* d_kblocks = nullptr;        // non-zero 32-position K blocks of d_melfb_slots
   int n_kblocks = 0;
+  int melfb_cols = 0;              // columns of d_melfb_slots (n_mels rounded up to 128)
   // banded view of the filterbank for InverseMelScale (valid when imel_ok)
   bool imel_ok = false;
   std::string imel_why;
@@ -123,7 +124,9 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     // slot-ordered copy: row of slot position p = filterbank row of its bin for PRIMARY slots, zero for
     // the 440 duplicate slots and the 3 padding positions, so a GEMM over slot order equals the
     // reference's GEMM over bins up to summation order
-    std::vector<float> fbs((size_t)kFrameStride * M, 0.f);
+    const int Mp = (M + 127) / 128 * 128;  // columns padded to the GEMM's 128-row tile: aligned, test-free loads
+    pl->melfb_cols = Mp;
+    std::vector<float> fbs((size_t)kFrameStride * Mp, 0.f);
     std::vector<char> seen(kBins, 0);
     for (int k1 = 0; k1 < 21; ++k1)
       for (int ka = 0; ka < 21; ++ka)
@@ -133,7 +136,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
           if (seen[bin]) continue;
           seen[bin] = 1;
           const int pos = slot_pos_f(k1 * 21 + ka, kb);
-          memcpy(&fbs[(size_t)pos * M], &h_melfb[(size_t)bin * M], M * sizeof(float));
+          memcpy(&fbs[(size_t)pos * Mp], &h_melfb[(size_t)bin * M], M * sizeof(float));
         }
     RFX_HIP(hipMalloc(&pl->d_melfb_slots, fbs.size() * sizeof(float)));
     RFX_HIP(hipMemcpy(pl->d_melfb_slots, fbs.data(), fbs.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -143,7 +146,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       bool nz = false;
       for (int r = blk * 32; r < blk * 32 + 32 && !nz; ++r)
         for (int m = 0; m < M; ++m)
-          if (fbs[(size_t)r * M + m] != 0.f) { nz = true; break; }
+          if (fbs[(size_t)r * Mp + m] != 0.f) { nz = true; break; }
       if (nz) kb.push_back(blk);
     }
     pl->n_kblocks = (int)kb.size();
@@ -472,6 +475,7 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
   a.n_kblocks = plan->n_kblocks;
   a.out = d_mel_out;
   a.M = plan->p.n_mels;
+  a.Mp = plan->melfb_cols;
   a.T = 1 + Lw / kHop;
   a.N = B * a.T;
   RFX_HIP(launch_mel_gemm(a, (hipStream_t)stream));
@@ -492,6 +496,7 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
   a.n_kblocks = plan->n_kblocks;
   a.out = d_mel_out;
   a.M = plan->p.n_mels;
+  a.Mp = plan->melfb_cols;
   a.T = T;
   a.N = B * T;
   RFX_HIP(launch_mel_gemm(a, (hipStream_t)stream));

@@ -48,11 +48,11 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t stream);
 // mel projection GEMM: out[b][m][t] = sum_p fbs[p][m] * mag[b*T+t][p]
 struct MelArgs {
   const float* mag;     // [N][kFrameStride]
-  const float* fbs;     // [kFrameStride][M] slot-ordered filterbank
+  const float* fbs;     // [kFrameStride][Mp] slot-ordered filterbank, columns zero-padded to Mp
   const int* kblocks;   // indices of the 32-position K blocks that contain a non-zero filterbank row
   int n_kblocks;
   float* out;           // [B][M][T]
-  int M, N, T;          // N = B*T frames
+  int M, Mp, N, T;      // N = B*T frames, Mp = M rounded up to the 128-row tile
 };
 hipError_t launch_mel_gemm(const MelArgs& a, hipStream_t stream);
 

@@ -12,9 +12,17 @@
 // (rows = mel), the B operand the magnitudes (columns = frames), so each accumulator register holds
 // one mel row across 32 consecutive frames and the (B, M, T) store is 128 contiguous bytes per
 // register.  Workgroup = 4 waves = 128 mel x 128 frames, each wave 64 x 64 (2 x 2 MFMA tiles).
+//
+// Pipeline per K block (32 slot positions): the global loads of block i+1 are issued right after
+// block i has been written to LDS and fly during its 64 MFMAs; inside the block the LDS fragments of
+// step kp+1 are fetched before the MFMAs of step kp.  All global accesses are buffer-descriptor
+// addressed (rows beyond N read as zero through the descriptor's range check), the filterbank is
+// padded to a multiple of 128 columns at plan creation, so the loop has no bounds tests and the
+// kernel fits 3 workgroups per CU (accumulators in AGPRs).
 #include <hip/hip_runtime.h>
 
 #include "rfx_core.h"
+#include "rfx_frame.hip.h"
 #include "rfx_kernels.h"
 
 namespace rfx {
@@ -46,58 +54,74 @@ __global__ void __launch_bounds__(256) mel_gemm_kernel(MelArgs a) {
   //                      magnitude tile 128 x 32 floats = 1024 float4 -> 4 per thread (rows tid/8 + 32*i)
   const int fk = tid >> 5, fm4 = (tid & 31) * 4;
   const int gn = tid >> 3, gk4 = (tid & 7) * 4;
+  const int rows = min(kMelBN, a.N - n0);  // frames of this tile that exist
+  const rsrc_t rF = make_rsrc(a.fbs + m0, ((size_t)kFrameStride * a.Mp - m0) * sizeof(float));
+  const rsrc_t rG = make_rsrc(a.mag + (size_t)n0 * kFrameStride, (size_t)rows * kFrameStride * sizeof(float));
+  const unsigned offF = (unsigned)((fk * a.Mp + fm4) * sizeof(float));
+  const unsigned offG = (unsigned)((gn * kFrameStride + gk4) * sizeof(float));
+  const unsigned stepF = (unsigned)(8 * a.Mp * sizeof(float)), stepG = (unsigned)(32 * kFrameStride * sizeof(float));
+
+  v4f fv[4], gv[4];
+  auto fetch = [&](int bi) {
+    const int k0 = a.kblocks[bi] * kMelBK;
+    const unsigned sF = (unsigned)(k0 * a.Mp * sizeof(float)), sG = (unsigned)(k0 * sizeof(float));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fv[i] = ld4(rF, offF + i * stepF, sF);
+      gv[i] = ld4(rG, offG + i * stepG, sG);  // rows >= N are outside the descriptor: zero
+    }
+  };
+  fetch(0);
 
   for (int bi = 0; bi < a.n_kblocks; ++bi) {
-    const int k0 = a.kblocks[bi] * kMelBK;
-    float4 fv[4], gv[4];
+    __syncthreads();  // previous block's fragment reads are done
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = k0 + fk + 8 * i, m = m0 + fm4;
-      if (m + 3 < a.M && (a.M & 3) == 0) {
-        fv[i] = *reinterpret_cast<const float4*>(a.fbs + (size_t)k * a.M + m);
-      } else {
-        float t4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < 4; ++c)
-          if (m + c < a.M) t4[c] = a.fbs[(size_t)k * a.M + m + c];
-        fv[i] = float4{t4[0], t4[1], t4[2], t4[3]};
-      }
-      const int n = n0 + gn + 32 * i;
-      gv[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.mag + (size_t)n * kFrameStride + k0 + gk4)
-                        : float4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();  // previous step's reads are done
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(&Fs[fk + 8 * i][fm4]) = fv[i];
+      *reinterpret_cast<v4f*>(&Fs[fk + 8 * i][fm4]) = fv[i];
       float* d = &Ms[gn + 32 * i][gk4];
       d[0] = gv[i].x; d[1] = gv[i].y; d[2] = gv[i].z; d[3] = gv[i].w;
     }
     __syncthreads();
+    if (bi + 1 < a.n_kblocks) fetch(bi + 1);  // in flight during the 64 MFMAs below
+
+    float fa[2][2], fb[2][2];
+    auto frag = [&](int kp, int s) {
+      const int k = 2 * kp + lk;
+      fa[s][0] = Fs[k][wm + li];
+      fa[s][1] = Fs[k][wm + 32 + li];
+      fb[s][0] = Ms[wn + li][k];
+      fb[s][1] = Ms[wn + 32 + li][k];
+    };
+    frag(0, 0);
 #pragma unroll
     for (int kp = 0; kp < kMelBK / 2; ++kp) {
-      const int k = 2 * kp + lk;
-      const float a0 = Fs[k][wm + li], a1 = Fs[k][wm + 32 + li];
-      const float b0 = Ms[wn + li][k], b1 = Ms[wn + 32 + li][k];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const int s = kp & 1;
+      if (kp + 1 < kMelBK / 2) frag(kp + 1, s ^ 1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][1], acc[1][1], 0, 0, 0);
     }
   }
 
-  // C/D layout of 32x32 MFMA: col = lane & 31 (frame), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (mel)
+  // C/D layout of 32x32 MFMA: col = lane & 31 (frame), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (mel).
+  // Stores go through one descriptor based at the tile's first clip: per-lane offset = (clip, 4*lk, t),
+  // scalar offset = the wave-uniform part of the mel row; lanes past N get an out-of-range offset (dropped).
+  const int b0 = n0 / a.T;
+  const size_t clip_floats = (size_t)a.M * a.T;
+  const rsrc_t rO = make_rsrc(a.out + b0 * clip_floats, ((size_t)a.N * a.M - b0 * clip_floats) * sizeof(float));
+  const bool full_m = m0 + kMelBM <= a.M;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn + 32 * j + li;
-    if (n >= a.N) continue;
     const int b = n / a.T, t = n - b * a.T;
-    float* dst = a.out + (size_t)b * a.M * a.T + t;
+    const unsigned voff = n < a.N ? (unsigned)((((b - b0) * a.M + 4 * lk) * a.T + t) * sizeof(float)) : 0xFFFFFFFFu;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m < a.M) dst[(size_t)m * a.T] = acc[i][j][r];
+        const int mu = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2);  // wave-uniform part of the row
+        if (full_m || mu + 4 * lk < a.M) st1(acc[i][j][r], rO, voff, (unsigned)(mu * a.T * sizeof(float)));
       }
   }
 }
