@@ -34,32 +34,44 @@ __global__ void __launch_bounds__(256) image_decode_kernel(const uint8_t* __rest
   }
 }
 
-// ---- per-clip maximum (of x or |x|) over `count` contiguous floats; one workgroup per clip.
+// ---- per-clip maximum (of x or |x|) over `count` contiguous floats.  A clip is split over several
+// workgroups (float4 loads); partial maxima meet in an atomicMax on an order-preserving integer key
+// (positive NaN is the largest key, so np.max's NaN propagation comes for free), a last tiny kernel
+// turns the keys back into floats in place.
+__device__ __forceinline__ unsigned max_key(float v) {
+  unsigned b = __float_as_uint(v);
+  if (v != v) b = 0x7FC00000u;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
 template <bool ABS>
-__global__ void __launch_bounds__(1024) clip_max_kernel(const float* __restrict__ x, float* __restrict__ out, size_t count) {
-  __shared__ float red[16];
-  const float* p = x + (size_t)blockIdx.x * count;
-  float m = -__builtin_inff();
-  bool nan = false;
-  for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
-    float v = p[i];
-    if (ABS) v = fabsf(v);
-    nan |= (v != v);
-    m = fmaxf(m, v);
+__global__ void __launch_bounds__(256) clip_max_kernel(const float* __restrict__ x, unsigned* __restrict__ keys, size_t count, int splits) {
+  __shared__ unsigned red[4];
+  const int clip = blockIdx.x / splits, part = blockIdx.x - clip * splits;
+  const size_t chunk = (((count + splits - 1) / splits) + 3) & ~(size_t)3;
+  const size_t begin = (size_t)part * chunk, end = begin + chunk < count ? begin + chunk : count;
+  const float* p = x + (size_t)clip * count;
+  unsigned m = 0;  // key of the smallest value
+  auto take = [&](float v) { m = max(m, max_key(ABS ? fabsf(v) : v)); };
+  size_t i = begin;
+  if ((reinterpret_cast<uintptr_t>(p + begin) & 15) == 0) {
+    for (i = begin + 4 * (size_t)threadIdx.x; i + 3 < end; i += 4 * 256) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i);
+      take(v.x); take(v.y); take(v.z); take(v.w);
+    }
+    i = begin + ((end > begin ? end - begin : 0) & ~(size_t)3);  // scalar tail starts here
   }
-  if (nan) m = __builtin_nanf("");  // np.max propagates NaN
+  for (i += threadIdx.x; i < end; i += 256) take(p[i]);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float other = __shfl_xor(m, o);
-    m = (m != m || other != other) ? __builtin_nanf("") : fmaxf(m, other);
-  }
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float r = red[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = (r != r || red[i] != red[i]) ? __builtin_nanf("") : fmaxf(r, red[i]);
-    out[blockIdx.x] = r;
-  }
+  if (threadIdx.x == 0) atomicMax(&keys[clip], max(max(red[0], red[1]), max(red[2], red[3])));
+}
+__global__ void clip_max_finish_kernel(unsigned* keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) reinterpret_cast<float*>(keys)[i] = key_value(keys[i]);
 }
 
 // ---- encode: image_util.image_from_spectrogram (:27-54).  mel (N*C, M, T) -> img (N, M, T, 3) uint8.
@@ -132,8 +144,15 @@ hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out,
   return hipGetLastError();
 }
 hipError_t launch_clip_max(const float* x, float* out, int nclips, size_t count, bool abs_value, hipStream_t s) {
-  if (abs_value) hipLaunchKernelGGL(clip_max_kernel<true>, dim3(nclips), dim3(1024), 0, s, x, out, count);
-  else hipLaunchKernelGGL(clip_max_kernel<false>, dim3(nclips), dim3(1024), 0, s, x, out, count);
+  unsigned* keys = reinterpret_cast<unsigned*>(out);
+  hipError_t e = hipMemsetAsync(keys, 0, sizeof(unsigned) * nclips, s);
+  if (e != hipSuccess) return e;
+  // ~16 K floats per workgroup, at most 64 workgroups per clip
+  int splits = (int)((count + 16383) / 16384);
+  splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+  if (abs_value) hipLaunchKernelGGL(clip_max_kernel<true>, dim3(nclips * splits), dim3(256), 0, s, x, keys, count, splits);
+  else hipLaunchKernelGGL(clip_max_kernel<false>, dim3(nclips * splits), dim3(256), 0, s, x, keys, count, splits);
+  hipLaunchKernelGGL(clip_max_finish_kernel, dim3((nclips + 255) / 256), dim3(256), 0, s, keys, nclips);
   return hipGetLastError();
 }
 hipError_t launch_image_encode(const float* mel, const float* clip_max, const float* thr, uint8_t* img, int N, int M, int T,
