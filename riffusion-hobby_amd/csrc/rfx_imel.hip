@@ -357,30 +357,44 @@ imel_group_kernel_perwave(ImelArgs a) {
   }
 }
 
-// one thread per clip: replays the reference's stopping rule on the clip-mean loss
-__global__ void imel_scan_kernel(const float* __restrict__ loss_hist, int* __restrict__ it_stop, int* __restrict__ any_early,
-                                 int nclips, int C, int T, int max_iter, float tol_loss, float tol_change) {
+// one workgroup per clip: replays the reference's stopping rule on the clip-mean loss.  Thread (g, i) sums
+// iteration i over every fourth frame (loads coalesce across i), the four partial sums meet in LDS, then one
+// thread walks the max_iter means.
+__global__ void __launch_bounds__(1024) imel_scan_kernel(const float* __restrict__ loss_hist, int* __restrict__ it_stop,
+                                                        int* __restrict__ any_early, int nclips, int C, int T, int max_iter,
+                                                        float tol_loss, float tol_change) {
+  extern __shared__ float scan_smem[];  // [4][256] partial sums, then [max_iter] means
+  float* part = scan_smem;
+  float* mean = scan_smem + 1024;
   const int clip = blockIdx.x;
   if (clip >= nclips) return;
-  __shared__ float red[256];
   const int nframes = C * T;
-  float prev = __builtin_inff();
-  int stop = max_iter;
-  for (int it = 0; it < max_iter; ++it) {
-    float s = 0.f;
-    for (int f = threadIdx.x; f < nframes; f += blockDim.x) s += loss_hist[((size_t)clip * nframes + f) * max_iter + it];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
+  const int i = threadIdx.x & 255, g = threadIdx.x >> 8;
+  const float* base = loss_hist + (size_t)clip * nframes * max_iter;
+  for (int it0 = 0; it0 < max_iter; it0 += 256) {
+    const int it = it0 + i;
+    float s0 = 0.f, s1 = 0.f;
+    if (it < max_iter) {
+      int f = g;
+      for (; f + 4 < nframes; f += 8) {
+        s0 += base[(size_t)f * max_iter + it];
+        s1 += base[(size_t)(f + 4) * max_iter + it];
+      }
+      if (f < nframes) s0 += base[(size_t)f * max_iter + it];
     }
-    const float loss = red[0] / (float)nframes;
+    part[g * 256 + i] = s0 + s1;
     __syncthreads();
-    if (loss < tol_loss || fabsf(prev - loss) < tol_change) { stop = it + 1; break; }
-    prev = loss;
+    if (g == 0 && it < max_iter) mean[it] = ((part[i] + part[256 + i]) + (part[512 + i] + part[768 + i])) / (float)nframes;
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
+    float prev = __builtin_inff();
+    int stop = max_iter;
+    for (int it = 0; it < max_iter; ++it) {
+      const float loss = mean[it];
+      if (loss < tol_loss || fabsf(prev - loss) < tol_change) { stop = it + 1; break; }
+      prev = loss;
+    }
     it_stop[clip] = stop;
     if (stop < max_iter) atomicExch(any_early, 1);
   }
@@ -411,7 +425,7 @@ hipError_t launch_imel(const ImelArgs& a, hipStream_t stream) {
 
 hipError_t launch_imel_scan(const float* loss_hist, int* it_stop, int* any_early, int nclips, int C, int T, int max_iter,
                             float tol_loss, float tol_change, hipStream_t stream) {
-  hipLaunchKernelGGL(imel_scan_kernel, dim3(nclips), dim3(256), 0, stream, loss_hist, it_stop, any_early, nclips, C, T,
+  hipLaunchKernelGGL(imel_scan_kernel, dim3(nclips), dim3(1024), sizeof(float) * (1024 + (size_t)max_iter), stream, loss_hist, it_stop, any_early, nclips, C, T,
                      max_iter, tol_loss, tol_change);
   return hipGetLastError();
 }
