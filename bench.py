@@ -7,6 +7,7 @@ resident in HBM) -> image decode -> InverseMelScale (SGD 200) -> Griffin-Lim 32 
 HIP kernels through librfx.so.  One "step" = one such batch.  value = tiles/s over all ranks.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --workload forward        # secondary line: configs[2], audio -> mel images (MFMA roofline)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Clips are independent, so N GPUs each process their own 64 tiles (weak scaling, no data-path
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
     ap.add_argument("--iters", type=int, default=32, help="Griffin-Lim iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["decode", "forward"], default="decode",
+                    help="decode = the headline (tiles -> audio); forward = BASELINE.json configs[2] (audio -> mel images)")
     return ap.parse_args()
 
 
@@ -102,6 +105,138 @@ def cpu_baseline(iters: int, threads_cap: int = 16, min_seconds: float = 10.0, m
     }
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def executed_mel_k(n_mels: int = N_MELS) -> int:
+    """K the mel GEMM really multiplies: 32-position blocks of the slot-ordered filterbank that hold a non-zero
+    row (the list rfx_plan_create builds; positions follow slot_pos_f of csrc/rfx_core.h)."""
+    from riffusion import _hip
+
+    fb = np.asarray(_hip.mel_filterbank(N_BINS, 0.0, 10000.0, n_mels, SR, None, "htk"))
+    live_bin = np.abs(fb).sum(1) > 0
+    live = np.zeros(9408, bool)
+    for k1 in range(21):
+        for kp in range(441):
+            k = k1 + 40 * kp
+            q, kb = k1 * 21 + kp % 21, kp // 21
+            qp = q + q // 63
+            pos = ((kb >> 2) * 448 + qp) * 4 + (kb & 3) if kb < 20 else 20 * 448 + qp
+            live[pos] = live_bin[k if k <= 8820 else 17640 - k]
+    return 32 * int(live.reshape(-1, 32).any(1).sum())
+
+
+def forward_cpu_baseline(threads_cap: int = 16, min_seconds: float = 10.0):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import riffusion_oracle as O  # reported baseline only
+
+    threads = max(1, min(os.cpu_count() or 1, threads_cap))
+    torch.set_num_threads(threads)
+    p = O.OracleParams()
+    rng = np.random.default_rng(20240807)
+    n, t0 = 0, time.time()
+    while n == 0 or time.time() - t0 < min_seconds:
+        wave = torch.from_numpy((rng.standard_normal((1, HOP * (N_FRAMES - 1))) * 8000).astype(np.float32))
+        mel = O.mel_amplitudes_from_waveform(wave, p)
+        O.image_u8_from_spectrogram(mel.numpy(), 0.25)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} synthetic waveforms of {HOP * (N_FRAMES - 1)} samples, one reference call each (torch.stft + dense "
+                      f"mel matmul + uint8 quantisation), {dt:.1f} s, {threads} threads of {os.cpu_count()} logical cores"}
+
+
+def forward_main(args, world, rank, dev, distributed):
+    """BASELINE.json configs[2]: B waveforms -> STFT -> MFMA mel GEMM -> uint8 image, per rank."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import image_util
+
+    if distributed:
+        import torch.distributed as dist
+    plan = _hip.get_plan(SpectrogramParams(), dev)
+    B, L = args.batch, HOP * (N_FRAMES - 1)
+    rng = np.random.default_rng(20240807 + rank)
+    wave = torch.from_numpy((rng.standard_normal((B, L)) * 8000).astype(np.float32)).to(dev)
+    thr = torch.from_numpy(image_util.encode_thresholds(0.25)).to(dev)
+
+    def step():
+        mel = plan.mel_from_waveform(wave)
+        return plan.image_encode(mel, False, thr)[0]
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert img.shape == (B, N_MELS, N_FRAMES, 3)
+    if rank == 0:
+        def timed(fn, reps=5):  # one call per measurement, drained before and after: no overlap between launches
+            tot = 0.0
+            for _ in range(reps):
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                res = fn()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                tot += e0.elapsed_time(e1)
+            return tot / reps, res
+
+        stft_ms, _ = timed(lambda: plan.stft(wave, want_mag=True, want_spec=False))
+        mel_ms, mel = timed(lambda: plan.mel_from_waveform(wave))
+        enc_ms, _ = timed(lambda: plan.image_encode(mel, False, thr))
+        gemm_ms = mel_ms - stft_ms  # mel_from_waveform = stft_kernel + mel_gemm_kernel on one stream
+        k_exec = executed_mel_k()
+        tflops = 2.0 * N_MELS * k_exec * B * N_FRAMES / (gemm_ms * 1e-3) / 1e12
+        images_per_s = world * B * args.steps / elapsed
+        out = {
+            "metric": "spectrogram_images_per_sec_forward",
+            "value": round(images_per_s, 1),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"batch={B} synthetic waveforms of {L} samples -> STFT -> MFMA mel GEMM -> uint8 image "
+                                   "(BASELINE.json configs[2]); waveforms resident in HBM",
+                       "batch_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"clips sharded over {world} GPU(s), no data-path collective"},
+            "audio_sec_per_sec": round(images_per_s * L / SR, 1),
+            "roofline": {"kernel": "rfx::mel_gemm_kernel", "bound": "mfma", "achieved": round(tflops, 1),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "executed_k": k_exec, "avg_launch_ms": round(gemm_ms, 4),
+                         "dense_equivalent_tflops": round(2.0 * N_MELS * N_BINS * B * N_FRAMES / (gemm_ms * 1e-3) / 1e12, 1),
+                         "note": "flops = 2 x 512 mel x executed K x frames (all-zero filterbank blocks are skipped); launch time = "
+                                 "mel_from_waveform minus stft on the same stream (torch events on the launch stream)"},
+            "stages": {"stft_ms": round(stft_ms, 3), "mel_gemm_ms": round(gemm_ms, 3), "image_encode_ms": round(enc_ms, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = forward_cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,6 +251,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if distributed else 0)
     torch.cuda.set_device(dev)
+    if args.workload == "forward":
+        return forward_main(args, world, rank, dev, distributed)
 
     from riffusion import _hip
     from riffusion.spectrogram_params import SpectrogramParams
