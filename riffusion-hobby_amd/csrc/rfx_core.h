@@ -46,6 +46,11 @@ constexpr int kQPad = 448;          // 441 owner threads padded to 7 waves x 64 
 constexpr int kFrameStride = 9408;  // 21 * 448 positions per frame in HBM: every wave-load is whole 128-B lines
 constexpr int kWinHops = 10;     // win_length / hop
 constexpr int kHalfHops = 5;     // frame t is centred on sample 441*t: it spans hop blocks t-5 .. t+4
+#ifndef RFX_ROW_STRIDE
+#define RFX_ROW_STRIDE 441
+#endif
+constexpr int kRowStride = RFX_ROW_STRIDE;          // LDS elements between cube rows (>= 441)
+constexpr int kCubeElems = 20 * kRowStride + kHop;
 constexpr int kThreads = 448;    // 7 waves x 64; lane 63 of every wave idles (7 x 63 = 441)
 
 RFX_HD cf cmul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -308,7 +313,7 @@ RFX_HD void p1_inverse(const cf (&V)[21], float (&y)[10]) {
 // ------------------------------------------------------------------------------------------------
 // LDS "cube" addressing: element (k1, a|ka, b) of the 21 x 21 x 21 work array
 // ------------------------------------------------------------------------------------------------
-RFX_HD int cube_at(int k1, int a, int b) { return (k1 * 21 + a) * 21 + b; }
+RFX_HD int cube_at(int k1, int a, int b) { return k1 * kRowStride + a * 21 + b; }
 
 // Twiddles are passed as accessors `tw(i) -> cf` so that the kernels can stream them from a table
 // (L2 / LDS) exactly where they are consumed instead of pinning 42 registers per table, while the
@@ -319,14 +324,14 @@ template <class TW>
 RFX_HD void p1_store(const cf (&v)[21], TW tw1, cf* cube, int npr) {
   cube[npr] = v[0];
 #pragma unroll
-  for (int k1 = 1; k1 < 21; ++k1) cube[k1 * kHop + npr] = cmul(v[k1], tw1(k1));
+  for (int k1 = 1; k1 < 21; ++k1) cube[k1 * kRowStride + npr] = cmul(v[k1], tw1(k1));
 }
 // P1' load: thread n' gathers rows k1 and removes the twiddle
 template <class TW>
 RFX_HD void p1_load(const cf* cube, TW tw1, cf (&V)[21], int npr) {
   V[0] = cube[npr];
 #pragma unroll
-  for (int k1 = 1; k1 < 21; ++k1) V[k1] = cmulc(cube[k1 * kHop + npr], tw1(k1));
+  for (int k1 = 1; k1 < 21; ++k1) V[k1] = cmulc(cube[k1 * kRowStride + npr], tw1(k1));
 }
 // P2 (forward, in place): thread (k1, b): DFT over a, then twiddle w441^{b*ka}
 template <class TW>

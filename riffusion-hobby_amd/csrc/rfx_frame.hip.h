@@ -56,7 +56,7 @@ __device__ __forceinline__ void st4(v4f v, rsrc_t r, unsigned voff, unsigned sof
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff, soff, AUX);
 }
 
-constexpr int kCubeBytes = kSlots * (int)sizeof(cf);        // 74 088
+constexpr int kCubeBytes = kCubeElems * (int)sizeof(cf);    // 74 088 at the dense row stride
 constexpr int kTw2Bytes = 21 * 21 * (int)sizeof(cf);        // 3 528
 constexpr int kFrameLdsBytes = kCubeBytes + kTw2Bytes;      // 77 616
 

@@ -30,7 +30,7 @@ extern "C" {
 
 // seg: 4410 windowed samples u[441*j+n'].  out: 9261 complex slots indexed [q=k1*21+ka][kb]
 void emu_forward(const float* seg, float* out_slots) {
-  std::vector<cf> tw1, tw2, cube(kSlots);
+  std::vector<cf> tw1, tw2, cube(kCubeElems);
   make_tables(tw1, tw2);
   for (int n = 0; n < 441; ++n) {  // P1
     float u[10];
@@ -59,7 +59,7 @@ void emu_forward(const float* seg, float* out_slots) {
 
 // in_slots: 9261 complex [q][kb] -> y: 4410 floats, y[441*j+n'] = sum (un-normalised, before 2/N*window)
 void emu_inverse(const float* in_slots, float* y) {
-  std::vector<cf> tw1, tw2, cube(kSlots);
+  std::vector<cf> tw1, tw2, cube(kCubeElems);
   make_tables(tw1, tw2);
   for (int k1 = 0; k1 < 21; ++k1)
     for (int ka = 0; ka < 21; ++ka) {
