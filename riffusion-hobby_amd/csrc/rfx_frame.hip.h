@@ -134,11 +134,9 @@ struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
 template <class Hook, class Pre = NoHook>
-__device__ __forceinline__ void frame_forward(const float (&u)[10], cf (&R)[21], const FrameCtx& f, const ThreadId& t,
-                                              Hook after_barrier, Pre before_barrier = Pre()) {
+__device__ __forceinline__ void frame_forward_tw(const float (&u)[10], cf (&R)[21], const FrameCtx& f, const ThreadId& t,
+                                                 const Tw1& tw, Hook after_barrier, Pre before_barrier = Pre()) {
   {
-    Tw1 tw;
-    load_tw1(tw, f);
     cf v[21];
     p1_forward(u, v);
     if (t.active) p1_store(v, [&tw](int k) { return tw.w[k]; }, f.cube, t.npr);
@@ -147,31 +145,45 @@ __device__ __forceinline__ void frame_forward(const float (&u)[10], cf (&R)[21],
   __syncthreads();
   after_barrier();
   {
-    const cf* tw = f.tw2s;
-    if (t.active) p2_forward(f.cube, [tw](int k) { return tw[k * 21]; }, t.k1, t.idx);
+    const cf* tw2 = f.tw2s;
+    if (t.active) p2_forward(f.cube, [tw2](int k) { return tw2[k * 21]; }, t.k1, t.idx);
   }
   wave_sync();
   p3_forward(f.cube, R, t.k1, t.idx);
 }
+template <class Hook, class Pre = NoHook>
+__device__ __forceinline__ void frame_forward(const float (&u)[10], cf (&R)[21], const FrameCtx& f, const ThreadId& t,
+                                              Hook after_barrier, Pre before_barrier = Pre()) {
+  Tw1 tw;
+  load_tw1(tw, f);
+  frame_forward_tw(u, R, f, t, tw, after_barrier, before_barrier);
+}
 
 // inverse transform of one frame: Z[21] (slots of thread q) -> y[10] (un-normalised hops of thread n')
+// `tw` is (re)loaded here, in flight across the barrier, and handed back to the caller: P1' and the next
+// frame's P1 use the same g(n')^k1 values (conjugated), so a Griffin-Lim iteration fetches them once per frame.
 template <class Pre = NoHook, class Post = NoHook>
-__device__ __forceinline__ void frame_inverse(cf (&Z)[21], float (&y)[10], const FrameCtx& f, const ThreadId& t,
-                                              Pre before_barrier = Pre(), Post after_barrier = Post()) {
+__device__ __forceinline__ void frame_inverse_tw(cf (&Z)[21], float (&y)[10], const FrameCtx& f, const ThreadId& t, Tw1& tw,
+                                                 Pre before_barrier = Pre(), Post after_barrier = Post()) {
   {
-    const cf* tw = f.tw2s;
-    if (t.active) p3_inverse(f.cube, Z, [tw](int k) { return tw[k * 21]; }, t.k1, t.idx);
+    const cf* tw2 = f.tw2s;
+    if (t.active) p3_inverse(f.cube, Z, [tw2](int k) { return tw2[k * 21]; }, t.k1, t.idx);
   }
   wave_sync();
   if (t.active) p2_inverse(f.cube, t.k1, t.idx);
-  Tw1 tw;
-  load_tw1(tw, f);  // in flight across the barrier
+  load_tw1(tw, f);
   before_barrier();
   __syncthreads();
   after_barrier();
   cf V[21];
   p1_load(f.cube, [&tw](int k) { return tw.w[k]; }, V, t.npr);
   p1_inverse(V, y);
+}
+template <class Pre = NoHook, class Post = NoHook>
+__device__ __forceinline__ void frame_inverse(cf (&Z)[21], float (&y)[10], const FrameCtx& f, const ThreadId& t,
+                                              Pre before_barrier = Pre(), Post after_barrier = Post()) {
+  Tw1 tw;
+  frame_inverse_tw(Z, y, f, t, tw, before_barrier, after_barrier);
 }
 
 }  // namespace rfx

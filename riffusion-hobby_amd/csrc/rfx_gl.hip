@@ -130,6 +130,8 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #else
 #define RFX_STAMP(i) ((void)0)
 #endif
+  Tw1 tw1;  // g(n')^k1 of this thread: fetched in the synthesis half, reused by the next frame's analysis
+  if (MODE != 0) load_tw1(tw1, f);
   for (int fr = t0; fr <= t1; ++fr) {
     const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
     const unsigned long long rng_base = ((unsigned long long)clip * g.T + fr) * kBins;
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #pragma unroll
       for (int kb = 0; kb < 21; ++kb) R[kb] = cf{u[kb % 10], u[(kb + 3) % 10]};
 #else
-      frame_forward(u, R, f, t,
+      frame_forward_tw(u, R, f, t, tw1,
                     [&] {
                       RFX_STAMP(1);
                       emit_scaled(pend_blk, pend_val);
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #else
 #ifdef RFX_PREFETCH_D
     // the next frame's new analysis sample goes in flight across the synthesis barrier
-    frame_inverse(R, y, f, t,
+    frame_inverse_tw(R, y, f, t, tw1,
                   [&] {
                     RFX_STAMP(4);
                     if (MODE != 0) d_next = load_d(fr + 10 - kHalfHops);
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
                   },
                   [&] { RFX_STAMP(5); });
 #else
-    frame_inverse(R, y, f, t, [&] { RFX_STAMP(4); }, [&] { RFX_STAMP(5); });
+    frame_inverse_tw(R, y, f, t, tw1, [&] { RFX_STAMP(4); }, [&] { RFX_STAMP(5); });
 #endif
 #endif
 #pragma unroll
