@@ -132,6 +132,7 @@ __device__ __forceinline__ void load_tw1(Tw1& tw, const FrameCtx& f) {
 // flight underneath P2/P3.
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
+  __device__ __forceinline__ void operator()(int) const {}
 };
 template <class Hook, class Pre = NoHook>
 __device__ __forceinline__ void frame_forward_tw(const float (&u)[10], cf (&R)[21], const FrameCtx& f, const ThreadId& t,
@@ -162,15 +163,17 @@ __device__ __forceinline__ void frame_forward(const float (&u)[10], cf (&R)[21],
 // inverse transform of one frame: Z[21] (slots of thread q) -> y[10] (un-normalised hops of thread n')
 // `tw` is (re)loaded here, in flight across the barrier, and handed back to the caller: P1' and the next
 // frame's P1 use the same g(n')^k1 values (conjugated), so a Griffin-Lim iteration fetches them once per frame.
-template <class Pre = NoHook, class Post = NoHook>
+template <class Pre = NoHook, class Post = NoHook, class Probe = NoHook>
 __device__ __forceinline__ void frame_inverse_tw(cf (&Z)[21], float (&y)[10], const FrameCtx& f, const ThreadId& t, Tw1& tw,
-                                                 Pre before_barrier = Pre(), Post after_barrier = Post()) {
+                                                 Pre before_barrier = Pre(), Post after_barrier = Post(), Probe probe = Probe()) {
   {
     const cf* tw2 = f.tw2s;
     if (t.active) p3_inverse(f.cube, Z, [tw2](int k) { return tw2[k * 21]; }, t.k1, t.idx);
   }
+  probe(0);  // timing builds only
   wave_sync();
   if (t.active) p2_inverse(f.cube, t.k1, t.idx);
+  probe(1);
   load_tw1(tw, f);
   before_barrier();
   __syncthreads();

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   __syncthreads();  // tw2 table in LDS
 
 #ifdef RFX_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = wall_clock64();
 #define RFX_STAMP(i) do { unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
 #else
@@ -164,6 +164,10 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
                     },
                     [&] { RFX_STAMP(0); });
       RFX_STAMP(2);
+#ifdef RFX_TIMING
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): how long the |S| stream is still outstanding after P3
+      RFX_STAMP(7);
+#endif
 #endif
       // ---- angles = a / (|a| + 1e-16);  next spectrum estimate Z = |S| * angles
 #pragma unroll
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
                     if (MODE != 0) d_next = load_d(fr + 10 - kHalfHops);
                     pend_scale = scale_of(fr - kHalfHops);
                   },
-                  [&] { RFX_STAMP(5); });
+                  [&] { RFX_STAMP(5); }, [&](int i) { RFX_STAMP(8 + i); });
 #else
     frame_inverse_tw(R, y, f, t, tw1, [&] { RFX_STAMP(4); }, [&] { RFX_STAMP(5); });
 #endif
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #ifdef RFX_TIMING
   if (g.timing && (threadIdx.x & 63) == 0) {
     const int w = threadIdx.x >> 6;
-    for (int i = 0; i < 8; ++i) g.timing[((size_t)blockIdx.x * 7 + w) * 8 + i] = tacc[i];
+    for (int i = 0; i < 12; ++i) g.timing[((size_t)blockIdx.x * 7 + w) * 12 + i] = tacc[i];
   }
 #endif
   // ---- flush the parked block and the right halo of the run

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "riffusion-hobby_amd"))
 import torch
 B, T = 64, 512
-tim = torch.zeros(B * 16 * 7 * 8, dtype=torch.int64, device="cuda")
+tim = torch.zeros(B * 16 * 7 * 12, dtype=torch.int64, device="cuda")
 os.environ["RFX_TIMING_PTR"] = str(tim.data_ptr())
 from riffusion import _hip
 from riffusion.spectrogram_params import SpectrogramParams
@@ -13,9 +13,10 @@ S = torch.rand(B * T, plan.frame_stride, device="cuda") * 1e6
 out = plan.griffinlim(S, B, T, 6, 0.99, seed=1)
 torch.cuda.synchronize()
 nb = int(os.environ.get("NBLK", 512))
-t = tim[: nb * 7 * 8].view(nb, 7, 8).double().cpu()
+t = tim[: nb * 7 * 12].view(nb, 7, 12).double().cpu()
 frames = T * B / nb
-names = ["in+P1 (to pre-barrier)", "barrier B1", "P2+P3", "middle (HBM)", "P3'+P2'+tw issue", "barrier B2", "P1'+OLA"]
+names = ["in+P1 (to pre-barrier)", "barrier B1", "P2+P3", "projection", "tw1/d issue (after P2')", "barrier B2", "P1'+OLA",
+         "wait for |S| (vmcnt 0)", "P3'", "wave sync + P2'"]
 tot = 0
 for i, n in enumerate(names):
     us = t[:, :, i].mean().item() / frames / 100.0  # 100 MHz ticks -> us
