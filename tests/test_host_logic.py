@@ -209,3 +209,35 @@ def test_pcm_segment_gain_filters():
         ref = pydub.AudioSegment(x.tobytes(), frame_rate=44100, sample_width=2, channels=2)
         ref = pydub.effects.normalize(ref.apply_gain(-12 - ref.dBFS), headroom=0.1)
         assert np.array_equal(np.array(ref.get_array_of_samples()), out.get_array_of_samples())
+
+
+def test_header_is_plain_c_and_links_from_c(repo_root, tmp_path):
+    """include/rfx.h is the whole boundary: it must compile as strict C99 (no C++ / torch types) and a C program
+    must link against librfx.so and call the entry points that need no GPU."""
+    import shutil
+    import subprocess
+
+    from riffusion import _hip
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "rfx.h"\n'
+        "int main(void) {\n"
+        "  rfx_params p = {44100, 17640, 4410, 441, 512, 200};\n"
+        "  rfx_plan* plan = 0;\n"
+        "  int rc = rfx_plan_create(&p, 0, 0, 0, &plan); /* null window: must be refused, not crash */\n"
+        '  printf("%d %d %d %d %s\\n", rfx_version() > 0, rfx_frame_stride(), rfx_num_bins(), rc, rfx_last_error());\n'
+        "  return 0;\n}\n"
+    )
+    exe = tmp_path / "abi"
+    lib_dir = os.path.dirname(_hip.library_path())
+    subprocess.run(
+        ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(repo_root, "include"), str(src),
+         "-o", str(exe), "-L", lib_dir, "-lrfx", f"-Wl,-rpath,{lib_dir}"],
+        check=True,
+    )
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(maxsplit=4)
+    assert out[:3] == ["1", "9408", "8821"]
+    assert int(out[3]) < 0 and "rfx_plan_create" in out[4]
