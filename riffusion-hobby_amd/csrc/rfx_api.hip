@@ -28,6 +28,60 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Every entry point runs on the device that owns its plan (or its buffers) and leaves the calling thread's
+// current device as it found it: torch tracks the current device per thread, and one process may hold plans
+// on several GPUs.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define RFX_ON_DEVICE(dev)   \
+  DeviceGuard guard_((dev)); \
+  if (guard_.err != hipSuccess) return fail(RFX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err))
+
+// device that owns a caller buffer (the codec entry points take no plan)
+int device_of(const void* d_ptr, int* device) {
+  hipPointerAttribute_t attr;
+  const hipError_t e = hipPointerGetAttributes(&attr, d_ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(RFX_ERR_INVALID, std::string("not a device pointer: ") + hipGetErrorString(e));
+  }
+  *device = attr.device;
+  return RFX_OK;
+}
+
+// HIP events of the timed Griffin-Lim entry point; released on every exit path
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  ~EventList() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+  hipError_t create(size_t n) {
+    ev.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+      hipEvent_t e;
+      const hipError_t rc = hipEventCreate(&e);
+      if (rc != hipSuccess) return rc;
+      ev.push_back(e);
+    }
+    return hipSuccess;
+  }
+};
 }  // namespace
 
 struct rfx_plan {
@@ -35,6 +89,9 @@ struct rfx_plan {
   int device;
   int num_cus;
   int n_stft;
+  int gl_wgs_per_cu = 1;    // resident Griffin-Lim workgroups per CU on this device (occupancy query at creation)
+  int imel_variant = 0;     // debugging override read once at creation: 0 = best, 1 = uniform groups, 2 = general
+  unsigned long long* timing = nullptr;  // RFX_TIMING builds only
   cf* d_tw1 = nullptr;      // [21][441]
   cf* d_tw2 = nullptr;      // [21][21]
   float* d_win = nullptr;   // [4410]
@@ -84,7 +141,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
   if (params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop)
     return fail(RFX_ERR_UNSUPPORTED,
                 "rfx_plan_create: only the 44.1 kHz geometry n_fft=17640 win=4410 hop=441 is implemented in HIP");
-  RFX_HIP(hipSetDevice(device));
+  RFX_ON_DEVICE(device);
   rfx_plan* pl = new rfx_plan();
   struct Guard {  // releases the half-built plan if any step below fails
     rfx_plan* p;
@@ -96,6 +153,15 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
   hipDeviceProp_t prop;
   RFX_HIP(hipGetDeviceProperties(&prop, device));
   pl->num_cus = prop.multiProcessorCount;
+  // per-device kernel attributes (dynamic LDS above 64 KB) and occupancy; environment knobs are read here,
+  // once, never on the hot calls
+  RFX_HIP(prepare_frame_kernels());
+  pl->gl_wgs_per_cu = gl_blocks_per_cu();
+  if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
+  pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : 0;
+#ifdef RFX_TIMING
+  if (const char* e = getenv("RFX_TIMING_PTR")) pl->timing = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
 
   const double PI2 = 6.283185307179586476925286766559;
   std::vector<cf> tw1(21 * kHop), tw2(21 * 21);
@@ -275,29 +341,35 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
 
 int rfx_plan_destroy(rfx_plan* plan) {
   if (!plan) return RFX_OK;
-  hipFree(plan->d_tw1);
-  hipFree(plan->d_tw2);
-  hipFree(plan->d_win);
-  hipFree(plan->d_melfb);
-  hipFree(plan->d_melfb_slots);
-  hipFree(plan->d_kblocks);
-  hipFree(plan->d_imel_blob);
+  {
+    DeviceGuard guard(plan->device);
+    (void)hipFree(plan->d_tw1);
+    (void)hipFree(plan->d_tw2);
+    (void)hipFree(plan->d_win);
+    (void)hipFree(plan->d_melfb);
+    (void)hipFree(plan->d_melfb_slots);
+    (void)hipFree(plan->d_kblocks);
+    (void)hipFree(plan->d_imel_blob);
+  }
   delete plan;
   return RFX_OK;
 }
 
 int rfx_pack_magnitudes(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_slots, void* stream) {
   if (!plan || !d_lin_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_pack_magnitudes: bad argument");
+  RFX_ON_DEVICE(plan->device);
   RFX_HIP(launch_pack_mag(d_lin_bft, d_slots, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
 int rfx_pack_complex(const rfx_plan* plan, const void* d_bft, int B, int T, void* d_slots, void* stream) {
   if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_pack_complex: bad argument");
+  RFX_ON_DEVICE(plan->device);
   RFX_HIP(launch_pack_angles((const cf*)d_bft, (cf*)d_slots, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
 int rfx_unpack_complex(const rfx_plan* plan, const void* d_slots, int B, int T, void* d_bft, void* stream) {
   if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_unpack_complex: bad argument");
+  RFX_ON_DEVICE(plan->device);
   RFX_HIP(launch_unpack_complex((const cf*)d_slots, (cf*)d_bft, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
@@ -307,6 +379,7 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
   if (!plan || !d_wave || B <= 0) return fail(RFX_ERR_INVALID, "rfx_stft: bad argument");
   // torch.stft(center=True, pad_mode="reflect") raises when the pad n_fft/2 is not smaller than the input
   if (Lw <= kNfft / 2) return fail(RFX_ERR_INVALID, "rfx_stft: reflect padding needs more than n_fft/2 = 8820 samples");
+  RFX_ON_DEVICE(plan->device);
   StftArgs a;
   a.wave = d_wave;
   a.mag = d_mag_slots;
@@ -358,6 +431,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   if (n_iter > 0 && kHop * (T - 1) <= kNfft / 2)
     return fail(RFX_ERR_INVALID, "rfx_griffinlim: Padding size should be less than the corresponding input dimension "
                                  "(reflect padding 8820 needs more than 8820 samples, i.e. at least 22 frames)");
+  RFX_ON_DEVICE(plan->device);
   hipStream_t stream = (hipStream_t)stream_;
   size_t off_audio, off_scale, total;
   int Lpad;
@@ -387,11 +461,10 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   g.Lpad = Lpad;
   g.mom = momentum / (1.f + momentum);
   g.seed = seed;
-  g.timing = nullptr;
-  if (const char* e = getenv("RFX_TIMING_PTR")) g.timing = (unsigned long long*)strtoull(e, nullptr, 0);
+  g.timing = plan->timing;
   // runs: fill every resident workgroup slot of the chip once; every run at least 10 frames long so
   // that a hop block is shared by at most two runs
-  const int slots = plan->num_cus * gl_blocks_per_cu();
+  const int slots = plan->num_cus * plan->gl_wgs_per_cu;
   int nruns = (slots + B - 1) / B;
   if (nruns > T / 10) nruns = T / 10;
   if (nruns < 1) nruns = 1;
@@ -399,10 +472,10 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   const int nblocks = B * nruns;
 
   // optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg)
-  std::vector<hipEvent_t> ev;
+  EventList events;
+  std::vector<hipEvent_t>& ev = events.ev;
   if (h_launch_ms) {
-    ev.resize(n_iter + 2);
-    for (auto& e : ev) RFX_HIP(hipEventCreate(&e));
+    RFX_HIP(events.create(n_iter + 2));
     RFX_HIP(hipEventRecord(ev[0], stream));
   }
   // generation indices: x_k lives in gen[k % 3]
@@ -427,7 +500,6 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   if (h_launch_ms) {
     RFX_HIP(hipEventSynchronize(ev[n_iter + 1]));
     for (int i = 0; i <= n_iter; ++i) RFX_HIP(hipEventElapsedTime(&h_launch_ms[i], ev[i], ev[i + 1]));
-    for (auto& e : ev) hipEventDestroy(e);
   }
   return RFX_OK;
 }
@@ -449,6 +521,7 @@ int rfx_griffinlim_timed(const rfx_plan* plan, const float* d_mag_slots, const v
 
 int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int T, float* d_bft, void* stream) {
   if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_unpack_magnitudes: bad argument");
+  RFX_ON_DEVICE(plan->device);
   RFX_HIP(launch_unpack_mag(d_slots, d_bft, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
@@ -465,6 +538,7 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
   if (!plan->d_melfb_slots) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: plan was created without a mel filterbank");
   if (workspace_bytes < rfx_mel_workspace_bytes(plan, B, Lw) || Lw <= kNfft / 2)
     return fail(Lw <= kNfft / 2 ? RFX_ERR_INVALID : RFX_ERR_WORKSPACE, "rfx_mel_from_waveform: input too short or workspace too small");
+  RFX_ON_DEVICE(plan->device);
   float* mag = (float*)d_workspace;
   int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
   if (rc) return rc;
@@ -487,6 +561,7 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
   if (!plan || !d_lin_bft || !d_mel_out || !d_workspace || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_mel_scale: bad argument");
   if (!plan->d_melfb_slots) return fail(RFX_ERR_INVALID, "rfx_mel_scale: plan was created without a mel filterbank");
   if (workspace_bytes < align_up((size_t)B * T * kFrameStride * sizeof(float), 256)) return fail(RFX_ERR_WORKSPACE, "rfx_mel_scale: workspace too small");
+  RFX_ON_DEVICE(plan->device);
   float* mag = (float*)d_workspace;
   RFX_HIP(launch_pack_mag(d_lin_bft, mag, B, T, (hipStream_t)stream));
   MelArgs a;
@@ -516,6 +591,7 @@ int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int 
   if (B <= 0 || T <= 0 || channels_per_clip <= 0 || B % channels_per_clip)
     return fail(RFX_ERR_INVALID, "rfx_inverse_mel: batch must be a multiple of channels_per_clip");
   if (workspace_bytes < rfx_inverse_mel_workspace_bytes(plan, B, T)) return fail(RFX_ERR_WORKSPACE, "rfx_inverse_mel: workspace too small");
+  RFX_ON_DEVICE(plan->device);
   hipStream_t stream = (hipStream_t)stream_;
   const int nclips = B / channels_per_clip;
   char* ws = (char*)d_workspace;
@@ -539,18 +615,21 @@ int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int 
   a.momentum = 0.9f;
   a.seed = seed;
   if (a.max_iter <= 0) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: max_mel_iters must be positive");
-  RFX_HIP(launch_imel(a, stream));
+  RFX_HIP(launch_imel(a, plan->imel_variant, stream));
   // reproduce the reference's early exit (tolerance_loss 1e-5, tolerance_change 1e-8,
   // spectrogram_converter.py:94-95): scan the clip losses, then re-run stopped clips for it_stop steps
   RFX_HIP(launch_imel_scan(hist, it_stop, any_early, nclips, channels_per_clip, T, a.max_iter, 1e-5f, 1e-8f, stream));
   a.it_limit = it_stop;
-  RFX_HIP(launch_imel(a, stream));
+  RFX_HIP(launch_imel(a, plan->imel_variant, stream));
   return RFX_OK;
 }
 
 int rfx_image_decode_u8(const uint8_t* d_img, int N, int H, int W, int stereo, const float* d_lut256, float* d_mel_out,
                         void* stream) {
   if (!d_img || !d_lut256 || !d_mel_out || N <= 0 || H <= 0 || W <= 0) return fail(RFX_ERR_INVALID, "rfx_image_decode_u8: bad argument");
+  int dev;
+  if (int rc = device_of(d_mel_out, &dev)) return rc;
+  RFX_ON_DEVICE(dev);
   RFX_HIP(launch_image_decode(d_img, d_lut256, d_mel_out, N, H, W, stereo ? 2 : 1, (hipStream_t)stream));
   return RFX_OK;
 }
@@ -559,6 +638,9 @@ int rfx_image_encode_u8(const float* d_mel, int N, int M, int T, int stereo, con
                         uint8_t* d_img_out, void* stream) {
   if (!d_mel || !d_thresholds255 || !d_clip_max || !d_img_out || N <= 0 || M <= 0 || T <= 0)
     return fail(RFX_ERR_INVALID, "rfx_image_encode_u8: bad argument");
+  int dev;
+  if (int rc = device_of(d_img_out, &dev)) return rc;
+  RFX_ON_DEVICE(dev);
   const int C = stereo ? 2 : 1;
   RFX_HIP(launch_clip_max(d_mel, d_clip_max, N, (size_t)C * M * T, false, (hipStream_t)stream));
   RFX_HIP(launch_image_encode(d_mel, d_clip_max, d_thresholds255, d_img_out, N, M, T, C, (hipStream_t)stream));
@@ -567,6 +649,9 @@ int rfx_image_encode_u8(const float* d_mel, int N, int M, int T, int stereo, con
 
 int rfx_pcm16(const float* d_wave, int N, int C, int L, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* stream) {
   if (!d_wave || !d_clip_peak || !d_pcm_out || N <= 0 || C <= 0 || L <= 0) return fail(RFX_ERR_INVALID, "rfx_pcm16: bad argument");
+  int dev;
+  if (int rc = device_of(d_pcm_out, &dev)) return rc;
+  RFX_ON_DEVICE(dev);
   if (normalize) RFX_HIP(launch_clip_max(d_wave, d_clip_peak, N, (size_t)C * L, true, (hipStream_t)stream));
   RFX_HIP(launch_pcm16(d_wave, d_clip_peak, d_pcm_out, N, L, C, normalize, (hipStream_t)stream));
   return RFX_OK;

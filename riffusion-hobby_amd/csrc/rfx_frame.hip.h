@@ -57,8 +57,16 @@ __device__ __forceinline__ void st4(v4f v, rsrc_t r, unsigned voff, unsigned sof
 }
 
 constexpr int kCubeBytes = kCubeElems * (int)sizeof(cf);    // 74 088 at the dense row stride
-constexpr int kTw2Bytes = 21 * 21 * (int)sizeof(cf);        // 3 528
-constexpr int kFrameLdsBytes = kCubeBytes + kTw2Bytes;      // 77 616
+// w441 twiddles in LDS, one row per idx = lane % 21: row[j] = w441^(idx * (j + 1)), j = 0..19, padded to 22
+// entries = 176 B so that a thread fetches its 20 twiddles with ten 16-byte reads and the 16 lanes of a
+// ds_read_b128 group (row stride 44 dwords) spread over all 64 banks.  A separate static array, not part of
+// the dynamic cube allocation: the compiler then knows that cube stores never alias twiddle reads (with one
+// shared base pointer it serialised every twiddle read behind the preceding cube store: 40 LDS round trips
+// per frame on the critical path).
+constexpr int kTw2Row = 22;
+constexpr int kTw2Bytes = 21 * kTw2Row * (int)sizeof(cf);   // 3 696 (static)
+constexpr int kFrameDynLdsBytes = kCubeBytes;               // dynamic part: the cube
+constexpr int kFrameLdsBytes = kCubeBytes + kTw2Bytes;      // 77 784 per workgroup in total
 
 struct ThreadId {
   int idx;   // lane % 21
@@ -81,7 +89,7 @@ __device__ __forceinline__ ThreadId thread_id() {
 
 struct FrameCtx {
   cf* cube;          // LDS
-  const cf* tw2s;    // LDS copy of tw2, [i][idx]
+  const v4f* tw2row; // LDS row of this thread's w441^(idx*k), k = 1..20, as ten 16-byte pairs
   rsrc_t tw1;        // global tw1[21][441]
   unsigned npr8;     // n' * sizeof(cf)
 };
@@ -89,11 +97,14 @@ struct FrameCtx {
 // copies the w441 table into LDS; the caller must barrier before the first transform
 __device__ __forceinline__ FrameCtx frame_ctx(char* smem, const ThreadId& t, const cf* __restrict__ tw1,
                                               const cf* __restrict__ tw2) {
+  __shared__ __attribute__((aligned(16))) cf tw2_lds[21 * kTw2Row];
   FrameCtx f;
   f.cube = reinterpret_cast<cf*>(smem);
-  cf* s = reinterpret_cast<cf*>(smem + kCubeBytes);
-  if (threadIdx.x < 441) s[threadIdx.x] = tw2[threadIdx.x];
-  f.tw2s = s + t.idx;
+  if (threadIdx.x < 420) {  // tw2 is symmetric: tw2[k][idx] == tw2[idx][k]
+    const int idx = threadIdx.x / 20, j = threadIdx.x - idx * 20;
+    tw2_lds[idx * kTw2Row + j] = tw2[idx * 21 + j + 1];
+  }
+  f.tw2row = reinterpret_cast<const v4f*>(tw2_lds + t.idx * kTw2Row);
   f.tw1 = make_rsrc(tw1, 21 * kHop * sizeof(cf));
   f.npr8 = (unsigned)t.npr * 8u;
   return f;
@@ -113,6 +124,29 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
+
+// the thread's 20 w441 twiddles (k = 1..20) come in as ten ds_read_b128, in two batches: k = 1..10 before
+// the butterflies (in flight underneath them), k = 11..20 once the first outputs have left their registers
+struct Tw2 {
+  cf w[21];
+};
+template <int HALF>
+__device__ __forceinline__ void load_tw2_half(Tw2& tw, const FrameCtx& f) {
+#pragma unroll
+  for (int i = HALF * 5; i < HALF * 5 + 5; ++i) {
+    const v4f p = f.tw2row[i];
+    tw.w[2 * i + 1] = cf{p.x, p.y};
+    tw.w[2 * i + 2] = cf{p.z, p.w};
+  }
+}
+struct Tw2Stage {
+  Tw2& tw;
+  const FrameCtx& f;
+  __device__ __forceinline__ void operator()(int s) const {
+    if (s == 0) load_tw2_half<0>(tw, f); else load_tw2_half<1>(tw, f);
+    RFX_SCHED_FENCE();
+  }
+};
 
 // the 20 non-trivial g(n')^k1 twiddles of this thread, fetched from the L2-resident table in one
 // burst so that their latency overlaps the butterflies / the barrier that precede their use
@@ -134,21 +168,19 @@ struct NoHook {
   __device__ __forceinline__ void operator()() const {}
   __device__ __forceinline__ void operator()(int) const {}
 };
-template <class Hook, class Pre = NoHook>
+template <class Hook, class Pre = NoHook, class Mid = NoHook>
 __device__ __forceinline__ void frame_forward_tw(const float (&u)[10], cf (&R)[21], const FrameCtx& f, const ThreadId& t,
-                                                 const Tw1& tw, Hook after_barrier, Pre before_barrier = Pre()) {
-  {
-    cf v[21];
-    p1_forward(u, v);
-    if (t.active) p1_store(v, [&tw](int k) { return tw.w[k]; }, f.cube, t.npr);
-  }
+                                                 const Tw1& tw, Hook after_barrier, Pre before_barrier = Pre(),
+                                                 Mid before_p3 = Mid()) {
+  if (t.active) p1_forward_store(u, [&tw](int k) { return tw.w[k]; }, f.cube, t.npr);
   before_barrier();
   __syncthreads();
   after_barrier();
-  {
-    const cf* tw2 = f.tw2s;
-    if (t.active) p2_forward(f.cube, [tw2](int k) { return tw2[k * 21]; }, t.k1, t.idx);
+  if (t.active) {
+    Tw2 w2;
+    p2_forward(f.cube, [&w2](int k) { return w2.w[k]; }, t.k1, t.idx, Tw2Stage{w2, f});
   }
+  before_p3();
   wave_sync();
   p3_forward(f.cube, R, t.k1, t.idx);
 }
@@ -166,9 +198,9 @@ __device__ __forceinline__ void frame_forward(const float (&u)[10], cf (&R)[21],
 template <class Pre = NoHook, class Post = NoHook, class Probe = NoHook>
 __device__ __forceinline__ void frame_inverse_tw(cf (&Z)[21], float (&y)[10], const FrameCtx& f, const ThreadId& t, Tw1& tw,
                                                  Pre before_barrier = Pre(), Post after_barrier = Post(), Probe probe = Probe()) {
-  {
-    const cf* tw2 = f.tw2s;
-    if (t.active) p3_inverse(f.cube, Z, [tw2](int k) { return tw2[k * 21]; }, t.k1, t.idx);
+  if (t.active) {
+    Tw2 w2;
+    p3_inverse(f.cube, Z, [&w2](int k) { return w2.w[k]; }, t.k1, t.idx, Tw2Stage{w2, f});
   }
   probe(0);  // timing builds only
   wave_sync();
@@ -178,9 +210,7 @@ __device__ __forceinline__ void frame_inverse_tw(cf (&Z)[21], float (&y)[10], co
   before_barrier();
   __syncthreads();
   after_barrier();
-  cf V[21];
-  p1_load(f.cube, [&tw](int k) { return tw.w[k]; }, V, t.npr);
-  p1_inverse(V, y);
+  p1_load_inverse(f.cube, [&tw](int k) { return tw.w[k]; }, y, t.npr);
 }
 template <class Pre = NoHook, class Post = NoHook>
 __device__ __forceinline__ void frame_inverse(cf (&Z)[21], float (&y)[10], const FrameCtx& f, const ThreadId& t,

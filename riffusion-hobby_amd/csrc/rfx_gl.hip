@@ -25,7 +25,6 @@
 // reader adds the two parity buffers, which keeps results bit-reproducible run to run.
 #include "rfx_frame.hip.h"
 #include "rfx_kernels.h"
-#include <stdlib.h>
 
 namespace rfx {
 
@@ -132,6 +131,14 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #endif
   Tw1 tw1;  // g(n')^k1 of this thread: fetched in the synthesis half, reused by the next frame's analysis
   if (MODE != 0) load_tw1(tw1, f);
+  // the thread's ten Hann samples w[441 j + n']: fetched with the twiddles (in flight across the synthesis
+  // barrier), used by the overlap-add and by the next frame's analysis
+  float wv[10];
+  auto load_window = [&] {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) wv[j] = ld1(win, npr4, (unsigned)j * (kHop * 4u));
+  };
+  if (MODE != 0) load_window();
   for (int fr = t0; fr <= t1; ++fr) {
     const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
     const unsigned long long rng_base = ((unsigned long long)clip * g.T + fr) * kBins;
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
       d[9] = load_d(fr + 9 - kHalfHops);
 #endif
 #pragma unroll
-      for (int j = 0; j < 10; ++j) u[j] = d[j] * ld1(win, npr4, (unsigned)j * (kHop * 4u));
+      for (int j = 0; j < 10; ++j) u[j] = d[j] * wv[j];
 #ifdef RFX_ABL_NOFFT
       mag_issue(mag, Ssrc, foff, q16);
 #pragma unroll
@@ -160,9 +167,16 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
                       RFX_STAMP(1);
                       emit_scaled(pend_blk, pend_val);
                       pend_blk = -1;
+#ifdef RFX_MAG_EARLY
                       mag_issue(mag, Ssrc, foff, q16);
+#endif
                     },
-                    [&] { RFX_STAMP(0); });
+                    [&] { RFX_STAMP(0); },
+                    [&] {
+#ifndef RFX_MAG_EARLY
+                      mag_issue(mag, Ssrc, foff, q16);  // |S| flies under P3 (its 21 registers are not live during P2)
+#endif
+                    });
       RFX_STAMP(2);
 #ifdef RFX_TIMING
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): how long the |S| stream is still outstanding after P3
@@ -213,16 +227,17 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
     frame_inverse_tw(R, y, f, t, tw1,
                   [&] {
                     RFX_STAMP(4);
+                    load_window();
                     if (MODE != 0) d_next = load_d(fr + 10 - kHalfHops);
                     pend_scale = scale_of(fr - kHalfHops);
                   },
                   [&] { RFX_STAMP(5); }, [&](int i) { RFX_STAMP(8 + i); });
 #else
-    frame_inverse_tw(R, y, f, t, tw1, [&] { RFX_STAMP(4); }, [&] { RFX_STAMP(5); });
+    frame_inverse_tw(R, y, f, t, tw1, [&] { RFX_STAMP(4); load_window(); }, [&] { RFX_STAMP(5); });
 #endif
 #endif
 #pragma unroll
-    for (int j = 0; j < 10; ++j) acc[j] = fmaf(y[j], ld1(win, npr4, (unsigned)j * (kHop * 4u)), acc[j]);
+    for (int j = 0; j < 10; ++j) acc[j] = fmaf(y[j], wv[j], acc[j]);
 #ifdef RFX_PREFETCH_D
     if (MODE != 0) {
       pend_val = acc[0] * pend_scale;
@@ -264,14 +279,7 @@ __global__ void gl_combine_kernel(const float* a0, const float* a1, float* out, 
 }
 
 hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t stream) {
-  const size_t lds = kFrameLdsBytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gl_iter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gl_iter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gl_iter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  const size_t lds = kFrameDynLdsBytes;
   switch (mode) {
     case 0: hipLaunchKernelGGL(gl_iter_kernel<0>, dim3(nblocks), dim3(kThreads), lds, stream, g); break;
     case 1: hipLaunchKernelGGL(gl_iter_kernel<1>, dim3(nblocks), dim3(kThreads), lds, stream, g); break;
@@ -280,17 +288,19 @@ hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t st
   return hipGetLastError();
 }
 
+// Called at plan creation with the plan's device current: HIP keeps function attributes per device, so
+// there is no process-wide "done" flag anywhere in this library.
+hipError_t prepare_gl_kernels() {
+  hipError_t e;
+  if ((e = hipFuncSetAttribute((const void*)gl_iter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)gl_iter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes)) != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)gl_iter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+}
+
 int gl_blocks_per_cu() {
-  static int cached = 0;
-  if (cached) return cached;
-  if (const char* e = getenv("RFX_GL_WGS_PER_CU")) {
-    cached = atoi(e) > 0 ? atoi(e) : 1;
-    return cached;
-  }
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gl_iter_kernel<2>, kThreads, kFrameLdsBytes) != hipSuccess || n < 1) n = 1;
-  cached = n;
-  return cached;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gl_iter_kernel<2>, kThreads, kFrameDynLdsBytes) != hipSuccess || n < 1) n = 1;
+  return n;
 }
 
 hipError_t launch_gl_combine(const float* a0, const float* a1, float* out, int B, int L, int Lpad, hipStream_t stream) {

@@ -400,10 +400,10 @@ __global__ void __launch_bounds__(1024) imel_scan_kernel(const float* __restrict
   }
 }
 
-hipError_t launch_imel(const ImelArgs& a, hipStream_t stream) {
-  if (a.tb.fast_ok && !getenv("RFX_IMEL_GENERAL")) {
+hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
+  if (a.tb.fast_ok && variant != 2) {
     const size_t lds = sizeof(float) * (4 * (a.M + 2) + 8 + a.max_iter);
-    if (a.tb.fast_ok >= 2 && !getenv("RFX_IMEL_UNIFORM"))
+    if (a.tb.fast_ok >= 2 && variant != 1)
       hipLaunchKernelGGL((imel_group_kernel_perwave<kImelLoCap[0], kImelHiCap[0], kImelLoCap[1], kImelHiCap[1], kImelLoCap[2], kImelHiCap[2],
                                                    kImelLoCap[3], kImelHiCap[3]>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
     else

@@ -24,7 +24,10 @@ struct GlArgs {
 };
 
 hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t stream);
-int gl_blocks_per_cu();  // resident Griffin-Lim workgroups per CU (occupancy query)
+// per-device set-up, called by rfx_plan_create with the plan's device current
+hipError_t prepare_frame_kernels();  // dynamic-LDS attributes of the STFT and Griffin-Lim kernels
+hipError_t prepare_gl_kernels();
+int gl_blocks_per_cu();  // resident Griffin-Lim workgroups per CU on the current device (occupancy query)
 hipError_t launch_gl_combine(const float* a0, const float* a1, float* out, int B, int L, int Lpad, hipStream_t stream);
 
 // layout conversion between the reference's (B, n_stft, T) tensors and slot-major frames
@@ -90,7 +93,7 @@ struct ImelArgs {
   float lr, momentum;
   unsigned long long seed;
 };
-hipError_t launch_imel(const ImelArgs& a, hipStream_t stream);
+hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream);  // variant: 0 best, 1 uniform groups, 2 general
 // scans loss_hist for the early-stop condition; it_stop[clip] = steps the reference would have run
 hipError_t launch_imel_scan(const float* loss_hist, int* it_stop, int* any_early, int nclips, int C, int T, int max_iter,
                             float tol_loss, float tol_change, hipStream_t stream);

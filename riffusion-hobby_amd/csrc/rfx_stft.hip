@@ -147,13 +147,13 @@ __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
   }
 }
 
+hipError_t prepare_frame_kernels() {
+  const hipError_t e = hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+  return e != hipSuccess ? e : prepare_gl_kernels();
+}
+
 hipError_t launch_stft(const StftArgs& a, hipStream_t stream) {
-  const size_t lds = kFrameLdsBytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  const size_t lds = kFrameDynLdsBytes;
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   hipLaunchKernelGGL(stft_kernel, dim3(a.B * chunks), dim3(kThreads), lds, stream, a);
   return hipGetLastError();

@@ -113,8 +113,19 @@ def check(status: int) -> None:
         raise RfxError(f"librfx error {status}: {msg.decode() if msg else '?'}")
 
 
-def current_stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def current_stream(device: T.Optional[torch.device] = None) -> int:
+    """torch's current stream ON `device` (not on the calling thread's current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def resolve_device(device: T.Union[str, torch.device]) -> torch.device:
+    """'cuda' -> the indexed device it means for the calling thread right now."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RfxError("the HIP path runs on the GPU only (device 'cuda'); there is no CPU implementation")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
 
 
 # ------------------------------------------------------------------------------------------------
@@ -191,10 +202,10 @@ class Plan:
         )
         cp = RfxParams(params.sample_rate, self.n_fft, self.win_length, self.hop_length, self.n_mels, params.max_mel_iters)
         handle = c_void_p()
-        index = device.index if device.index is not None else torch.cuda.current_device()
+        self.device = device = resolve_device(device)
         check(
             self.lib.rfx_plan_create(
-                ctypes.byref(cp), self.window.data_ptr(), self.melfb.data_ptr(), index, ctypes.byref(handle)
+                ctypes.byref(cp), self.window.data_ptr(), self.melfb.data_ptr(), device.index, ctypes.byref(handle)
             )
         )
         self.handle = handle
@@ -208,10 +219,14 @@ class Plan:
             pass
 
     # ---- thin typed wrappers -----------------------------------------------------------------
-    def _chk(self, t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-        if t.device.type != "cuda":
-            raise RfxError("HIP path needs tensors on the GPU")
-        return t.to(dtype).contiguous()
+    def _chk(self, t: torch.Tensor, dtype: T.Optional[torch.dtype] = None) -> torch.Tensor:
+        """Tensors must live on THIS plan's GPU: its constant tables do, and kernels are queued on that device's stream."""
+        if t.device != self.device:
+            raise RfxError(f"tensor on {t.device} handed to a plan that lives on {self.device}")
+        return (t if dtype is None else t.to(dtype)).contiguous()
+
+    def _stream(self) -> int:
+        return current_stream(self.device)
 
     def pack_magnitudes(self, lin_bft: torch.Tensor) -> torch.Tensor:
         lin_bft = self._chk(lin_bft, torch.float32)
@@ -219,19 +234,20 @@ class Plan:
         if F != self.n_stft:
             raise ValueError(f"expected {self.n_stft} linear bins, got {F}")
         out = torch.zeros((B * Tn, self.frame_stride), dtype=torch.float32, device=lin_bft.device)
-        check(self.lib.rfx_pack_magnitudes(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        check(self.lib.rfx_pack_magnitudes(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), self._stream()))
         return out
 
     def pack_complex(self, x_bft: torch.Tensor) -> torch.Tensor:
         x_bft = self._chk(x_bft, torch.complex64)
         B, F, Tn = x_bft.shape
         out = torch.zeros((B * Tn, self.frame_stride), dtype=torch.complex64, device=x_bft.device)
-        check(self.lib.rfx_pack_complex(self.handle, x_bft.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        check(self.lib.rfx_pack_complex(self.handle, x_bft.data_ptr(), B, Tn, out.data_ptr(), self._stream()))
         return out
 
     def unpack_complex(self, slots: torch.Tensor, B: int, Tn: int) -> torch.Tensor:
+        slots = self._chk(slots, torch.complex64)
         out = torch.empty((B, self.n_stft, Tn), dtype=torch.complex64, device=slots.device)
-        check(self.lib.rfx_unpack_complex(self.handle, slots.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        check(self.lib.rfx_unpack_complex(self.handle, slots.data_ptr(), B, Tn, out.data_ptr(), self._stream()))
         return out
 
     def stft(self, wave: torch.Tensor, want_mag: bool, want_spec: bool):
@@ -254,7 +270,7 @@ class Plan:
                 Lw,
                 mag.data_ptr() if mag is not None else None,
                 spec.data_ptr() if spec is not None else None,
-                current_stream(),
+                self._stream(),
             )
         )
         return mag, spec, Tn
@@ -271,7 +287,14 @@ class Plan:
         workspace: T.Optional[torch.Tensor] = None,
         launch_ms: T.Optional[T.Any] = None,
     ) -> torch.Tensor:
+        mag_slots = self._chk(mag_slots, torch.float32)
+        if angles0_slots is not None:
+            angles0_slots = self._chk(angles0_slots, torch.complex64)
+        if mag_slots.numel() < B * Tn * self.frame_stride:
+            raise ValueError(f"magnitude slots hold {mag_slots.numel()} values, {B} x {Tn} frames need {B * Tn * self.frame_stride}")
         need = self.lib.rfx_griffinlim_workspace_bytes(self.handle, B, Tn)
+        if workspace is not None:
+            workspace = self._chk(workspace)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=mag_slots.device)
         out = torch.empty((B, self.hop_length * (Tn - 1)), dtype=torch.float32, device=mag_slots.device)
@@ -289,7 +312,7 @@ class Plan:
                     out.data_ptr(),
                     workspace.data_ptr(),
                     workspace.numel(),
-                    current_stream(),
+                    self._stream(),
                     ctypes.cast(launch_ms, c_void_p),
                 )
             )
@@ -307,15 +330,16 @@ class Plan:
                 out.data_ptr(),
                 workspace.data_ptr(),
                 workspace.numel(),
-                current_stream(),
+                self._stream(),
             )
         )
         return out
 
 
     def unpack_magnitudes(self, slots: torch.Tensor, B: int, Tn: int) -> torch.Tensor:
+        slots = self._chk(slots, torch.float32)
         out = torch.empty((B, self.n_stft, Tn), dtype=torch.float32, device=slots.device)
-        check(self.lib.rfx_unpack_magnitudes(self.handle, slots.data_ptr(), B, Tn, out.data_ptr(), current_stream()))
+        check(self.lib.rfx_unpack_magnitudes(self.handle, slots.data_ptr(), B, Tn, out.data_ptr(), self._stream()))
         return out
 
     def mel_from_waveform(self, wave: torch.Tensor) -> torch.Tensor:
@@ -333,7 +357,7 @@ class Plan:
         out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=wave.device)
         check(
             self.lib.rfx_mel_from_waveform(
-                self.handle, wave.data_ptr(), B, Lw, out.data_ptr(), ws.data_ptr(), ws.numel(), current_stream()
+                self.handle, wave.data_ptr(), B, Lw, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()
             )
         )
         return out
@@ -346,7 +370,7 @@ class Plan:
             raise ValueError(f"expected {self.n_stft} linear bins, got {F}")
         ws = torch.empty(B * Tn * self.frame_stride * 4 + 256, dtype=torch.uint8, device=lin_bft.device)
         out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=lin_bft.device)
-        check(self.lib.rfx_mel_scale(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), ws.data_ptr(), ws.numel(), current_stream()))
+        check(self.lib.rfx_mel_scale(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
     def inverse_mel(
@@ -380,7 +404,7 @@ class Plan:
                 out.data_ptr(),
                 ws.data_ptr(),
                 ws.numel(),
-                current_stream(),
+                self._stream(),
             )
         )
         return out
@@ -390,16 +414,18 @@ class Plan:
         """(N, H, W, 3) uint8 -> (N*C, H, W) float32."""
         if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[-1] != 3:
             raise ValueError("expected (N, H, W, 3) uint8 images")
-        img_u8 = img_u8.contiguous()
+        img_u8 = self._chk(img_u8)
+        lut = self._chk(lut, torch.float32)
         N, H, W, _ = img_u8.shape
         C = 2 if stereo else 1
         out = torch.empty((N * C, H, W), dtype=torch.float32, device=img_u8.device)
-        check(self.lib.rfx_image_decode_u8(img_u8.data_ptr(), N, H, W, int(stereo), lut.data_ptr(), out.data_ptr(), current_stream()))
+        check(self.lib.rfx_image_decode_u8(img_u8.data_ptr(), N, H, W, int(stereo), lut.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
     def image_encode(self, mel: torch.Tensor, stereo: bool, thresholds: torch.Tensor):
         """(N*C, M, T) float32 -> ((N, M, T, 3) uint8, per-clip max (N,))."""
         mel = self._chk(mel, torch.float32)
+        thresholds = self._chk(thresholds, torch.float32)
         C = 2 if stereo else 1
         NC, M, Tn = mel.shape
         if NC % C:
@@ -407,7 +433,7 @@ class Plan:
         N = NC // C
         img = torch.empty((N, M, Tn, 3), dtype=torch.uint8, device=mel.device)
         mx = torch.empty((N,), dtype=torch.float32, device=mel.device)
-        check(self.lib.rfx_image_encode_u8(mel.data_ptr(), N, M, Tn, int(stereo), thresholds.data_ptr(), mx.data_ptr(), img.data_ptr(), current_stream()))
+        check(self.lib.rfx_image_encode_u8(mel.data_ptr(), N, M, Tn, int(stereo), thresholds.data_ptr(), mx.data_ptr(), img.data_ptr(), self._stream()))
         return img, mx
 
     def pcm16(self, wave: torch.Tensor, channels: int, normalize: bool = True):
@@ -419,21 +445,19 @@ class Plan:
         N = NC // channels
         pcm = torch.empty((N, L, channels), dtype=torch.int16, device=wave.device)
         peak = torch.zeros((N,), dtype=torch.float32, device=wave.device)
-        check(self.lib.rfx_pcm16(wave.data_ptr(), N, channels, L, int(normalize), peak.data_ptr(), pcm.data_ptr(), current_stream()))
+        check(self.lib.rfx_pcm16(wave.data_ptr(), N, channels, L, int(normalize), peak.data_ptr(), pcm.data_ptr(), self._stream()))
         return pcm, peak
 
 
-_plans: T.Dict[T.Tuple[T.Any, str], Plan] = {}
+_plans: T.Dict[T.Tuple[T.Any, int], Plan] = {}
 _plans_lock = threading.Lock()
 
 
 def get_plan(params: T.Any, device: T.Union[str, torch.device]) -> Plan:
     """Plans are immutable and cached per (frozen params, device): constructing a converter per
     request, as the reference's server does (server.py:159), costs a dictionary lookup."""
-    dev = torch.device(device)
-    if dev.type != "cuda":
-        raise RfxError("the HIP path runs on the GPU only (device 'cuda'); there is no CPU implementation")
-    key = (params, str(dev))
+    dev = resolve_device(device)  # 'cuda' is keyed by the GPU it means now, not bound for good to the first one used
+    key = (params, dev.index)
     with _plans_lock:
         plan = _plans.get(key)
         if plan is None:

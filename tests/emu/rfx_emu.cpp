@@ -35,10 +35,9 @@ void emu_forward(const float* seg, float* out_slots) {
   for (int n = 0; n < 441; ++n) {  // P1
     float u[10];
     for (int j = 0; j < 10; ++j) u[j] = seg[441 * j + n];
-    cf v[21], t1[21];
+    cf t1[21];
     for (int k = 0; k < 21; ++k) t1[k] = tw1[n * 21 + k];
-    p1_forward(u, v);
-    p1_store(v, [&](int k) { return t1[k]; }, cube.data(), n);
+    p1_forward_store(u, [&](int k) { return t1[k]; }, cube.data(), n);
   }
   for (int k1 = 0; k1 < 21; ++k1)  // P2
     for (int b = 0; b < 21; ++b) {
@@ -72,11 +71,10 @@ void emu_inverse(const float* in_slots, float* y) {
   for (int k1 = 0; k1 < 21; ++k1)
     for (int b = 0; b < 21; ++b) p2_inverse(cube.data(), k1, b);
   for (int n = 0; n < 441; ++n) {
-    cf V[21], t1[21];
+    cf t1[21];
     for (int k = 0; k < 21; ++k) t1[k] = tw1[n * 21 + k];
-    p1_load(cube.data(), [&](int k) { return t1[k]; }, V, n);
     float yy[10];
-    p1_inverse(V, yy);
+    p1_load_inverse(cube.data(), [&](int k) { return t1[k]; }, yy, n);
     for (int j = 0; j < 10; ++j) y[441 * j + n] = yy[j];
   }
 }
