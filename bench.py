@@ -7,11 +7,17 @@ resident in HBM) -> image decode -> InverseMelScale (SGD 200) -> Griffin-Lim 32 
 HIP kernels through librfx.so.  One "step" = one such batch.  value = tiles/s over all ranks.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python bench.py --workload forward        # secondary line: configs[2], audio -> mel images (MFMA roofline)
+    python bench.py --workload forward        # configs[2] alone: audio -> mel images (MFMA roofline)
+    python bench.py --workload decode-stereo64 --gpus 8   # configs[3]: 512 stereo tiles, Griffin-Lim 64, sharded
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Clips are independent, so N GPUs each process their own 64 tiles (weak scaling, no data-path
-collective; the only collectives are the timing barrier and the max-over-ranks reduction).
+`--gpus N` with N > 1 outside a torch.distributed launch re-launches this script under
+`torch.distributed.run` with N ranks (one process per GPU, backend nccl = RCCL); `n_gpus` on the JSON
+line is the number of ranks that answered an RCCL all_reduce, not the flag.  Clips are independent:
+the headline workload gives every GPU its own 64 tiles (weak scaling, no data-path collective; the only
+collectives are the timing barrier and the max-over-ranks reduction); `decode-stereo64` shards a FIXED
+batch of 512 stereo clips over the ranks with `riffusion.batch_shard.shard_range` (strong scaling).
+The headline line also carries the configs[2] forward measurement as a `"forward"` object.
 
 Extra objects on the JSON line:
   roofline     - the dominant kernel (rfx::gl_iter_kernel<2>, one Griffin-Lim iteration over the
@@ -47,9 +53,39 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
     ap.add_argument("--iters", type=int, default=32, help="Griffin-Lim iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["decode", "forward"], default="decode",
-                    help="decode = the headline (tiles -> audio); forward = BASELINE.json configs[2] (audio -> mel images)")
+    ap.add_argument("--workload", choices=["decode", "forward", "decode-stereo64"], default="decode",
+                    help="decode = the headline (configs[1], tiles -> audio); forward = configs[2] (audio -> mel images); "
+                         "decode-stereo64 = configs[3] (512 stereo tiles, Griffin-Lim 64, sharded over the ranks)")
+    ap.add_argument("--global-clips", type=int, default=512, help="decode-stereo64: clips in the sharded batch")
+    ap.add_argument("--no-forward", action="store_true", help="skip the embedded configs[2] forward measurement")
     return ap.parse_args()
+
+
+def relaunch_distributed(n_gpus: int) -> int:
+    """`python bench.py --gpus N` (N > 1, no RANK in the environment): run N ranks of this script under
+    torch.distributed.run on this node, one per GPU, rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def git_rev(path: str) -> str:
+    """Short hash of the last commit that touched `path` (provenance of numbers read from profiles/)."""
+    import subprocess
+
+    try:
+        return subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True,
+                              text=True, timeout=10).stdout.strip() or "untracked"
+    except Exception:
+        return "unknown"
 
 
 def pmc_summary():
@@ -146,8 +182,9 @@ def forward_cpu_baseline(threads_cap: int = 16, min_seconds: float = 10.0):
                       f"mel matmul + uint8 quantisation), {dt:.1f} s, {threads} threads of {os.cpu_count()} logical cores"}
 
 
-def forward_main(args, world, rank, dev, distributed):
-    """BASELINE.json configs[2]: B waveforms -> STFT -> MFMA mel GEMM -> uint8 image, per rank."""
+def forward_measure(args, world, rank, dev, distributed, with_cpu):
+    """BASELINE.json configs[2]: B waveforms -> STFT -> MFMA mel GEMM -> uint8 image, per rank.
+    Returns the result object on rank 0 (None elsewhere); every rank takes part in the timed region."""
     from riffusion import _hip
     from riffusion.spectrogram_params import SpectrogramParams
     from riffusion.util import image_util
@@ -196,13 +233,39 @@ def forward_main(args, world, rank, dev, distributed):
                 tot += e0.elapsed_time(e1)
             return tot / reps, res
 
-        stft_ms, _ = timed(lambda: plan.stft(wave, want_mag=True, want_spec=False))
-        mel_ms, mel = timed(lambda: plan.mel_from_waveform(wave))
+        mel_ms, mel = timed(lambda: plan.mel_from_waveform(wave))   # ONE launch: rfx::stft_mel_kernel
         enc_ms, _ = timed(lambda: plan.image_encode(mel, False, thr))
-        gemm_ms = mel_ms - stft_ms  # mel_from_waveform = stft_kernel + mel_gemm_kernel on one stream
-        k_exec = executed_mel_k()
-        tflops = 2.0 * N_MELS * k_exec * B * N_FRAMES / (gemm_ms * 1e-3) / 1e12
+        stft_ms, (mag, _, _) = timed(lambda: plan.stft(wave, want_mag=True, want_spec=False))  # standalone Spectrogram member
+        lin = plan.unpack_magnitudes(mag, B, N_FRAMES)
+        del mag
+        melscale_ms, _ = timed(lambda: plan.mel_scale(lin))          # standalone MelScale member: pack + MFMA GEMM
+        del lin
         images_per_s = world * B * args.steps / elapsed
+        # the fused kernel reads the waveform and writes the mel amplitudes: its algorithmic HBM bytes are tiny, the
+        # transform itself (fp32 VALU butterflies) is what takes the time
+        alg_bytes = 4.0 * B * (L + N_MELS * N_FRAMES)
+        dense_flop = B * (N_FRAMES * 2.5 * 17640 * np.log2(17640) + 2.0 * N_MELS * N_BINS * N_FRAMES)  # 4.94 GFLOP per tile
+        pmc_src = "profiles/forward_pmc_latest.json"
+        try:
+            with open(os.path.join(ROOT, pmc_src)) as fh:
+                fpmc = json.load(fh)
+        except Exception:
+            fpmc = {}
+        roof = {"kernel": "rfx::stft_mel_kernel", "bound": "hbm", "achieved": round(alg_bytes / (mel_ms * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (mel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic": fpmc.get("hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(mel_ms, 4),
+                "dense_equivalent_tflops": round(dense_flop / (mel_ms * 1e-3) / 1e12, 1),
+                "note": "fused framed transform -> |X| -> banded mel projection in one launch: the mel GEMM of the reference (4.6 of its "
+                        "4.94 GFLOP per tile) multiplies a banded filterbank (7 976 non-zeros of 4.5 M) and is evaluated as such on chip, "
+                        "so neither HBM nor the MFMA pipes bound this kernel; dense_equivalent_tflops prices the launch at the "
+                        "reference's dense flop count (label: dense-equivalent, SURVEY 8(d)); `binding` is the resource that does"}
+        valu = fpmc.get("SQ_INSTS_VALU_per_launch")
+        if valu:
+            got = valu / (mel_ms * 1e-3) / 1e9
+            roof["binding"] = {"bound": "valu", "unit": "G wave-instructions/s", "wave_instructions_per_launch": valu, "achieved": round(got, 1),
+                               "peak": 1228.8, "frac": round(got / 1228.8, 4), "sustained_peak": round(1024 / 1.13, 1),
+                               "frac_of_sustained": round(got / (1024 / 1.13), 4), "source": pmc_src, "git": git_rev(pmc_src)}
+        k_exec = executed_mel_k()
         out = {
             "metric": "spectrogram_images_per_sec_forward",
             "value": round(images_per_s, 1),
@@ -216,29 +279,79 @@ def forward_main(args, world, rank, dev, distributed):
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"batch={B} synthetic waveforms of {L} samples -> STFT -> MFMA mel GEMM -> uint8 image "
+            "config": {"workload": f"batch={B} synthetic waveforms of {L} samples -> fused STFT / |X| / banded mel kernel -> uint8 image "
                                    "(BASELINE.json configs[2]); waveforms resident in HBM",
                        "batch_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"clips sharded over {world} GPU(s), no data-path collective"},
             "audio_sec_per_sec": round(images_per_s * L / SR, 1),
-            "roofline": {"kernel": "rfx::mel_gemm_kernel", "bound": "mfma", "achieved": round(tflops, 1),
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "executed_k": k_exec, "avg_launch_ms": round(gemm_ms, 4),
-                         "dense_equivalent_tflops": round(2.0 * N_MELS * N_BINS * B * N_FRAMES / (gemm_ms * 1e-3) / 1e12, 1),
-                         "note": "flops = 2 x 512 mel x executed K x frames (all-zero filterbank blocks are skipped); launch time = "
-                                 "mel_from_waveform minus stft on the same stream (torch events on the launch stream)"},
-            "stages": {"stft_ms": round(stft_ms, 3), "mel_gemm_ms": round(gemm_ms, 3), "image_encode_ms": round(enc_ms, 3)},
+            "roofline": roof,
+            "stages": {"stft_mel_fused_ms": round(mel_ms, 3), "image_encode_ms": round(enc_ms, 3)},
+            # the reference's members are also available one by one (spectrogram_func, mel_scaler): unfused they cost
+            "standalone_members": {"spectrogram_stft_ms": round(stft_ms, 3), "mel_scale_pack_plus_mfma_gemm_ms": round(melscale_ms, 3),
+                                   "mfma_gemm_executed_k": k_exec,
+                                   "note": "MelScale on (B, n_stft, T) input = layout pack + fp32-MFMA GEMM over the non-zero K blocks"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if with_cpu:
             out["cpu_baseline"] = forward_cpu_baseline()
-        print(json.dumps(out), flush=True)
+        return out
+    return None
+
+
+def stereo64_main(args, world, rank, dev, distributed):
+    """BASELINE.json configs[3]: a fixed batch of `--global-clips` stereo 512x512 tiles, Griffin-Lim 64, sharded over the
+    ranks through the product entry point (SpectrogramImageConverter.audio_from_spectrogram_images(group=...)): every
+    rank decodes shard_range(N, world, rank) and the int16 PCM is all_gathered over RCCL."""
+    import torch.distributed as dist
+
+    from riffusion.spectrogram_image_converter import SpectrogramImageConverter
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    params = SpectrogramParams(stereo=True, num_griffin_lim_iters=64)
+    conv = SpectrogramImageConverter(params, device=str(dev))
+    N = args.global_clips
+    rng = np.random.default_rng(20240807)  # the SAME full batch on every rank
+    tiles = torch.from_numpy(rng.integers(0, 256, size=(N, N_MELS, N_FRAMES, 3), dtype=np.uint8)).to(dev)
+    group = dist.group.WORLD if distributed else None
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for w in range(args.warmup):
+        conv.audio_from_spectrogram_images(tiles[: 64 * world], seed=w, group=group)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        pcm = conv.audio_from_spectrogram_images(tiles, seed=100 + k, group=group)
+    sync_all()
+    elapsed = time.perf_counter() - t0
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert pcm.shape == (N, HOP * (N_FRAMES - 1), 2) and pcm.dtype == np.int16
+    if rank != 0:
+        return None
+    tiles_per_s = N * args.steps / elapsed
+    return {
+        "metric": "stereo_spectrogram_tiles_per_sec_griffinlim64", "value": round(tiles_per_s, 2), "unit": "tiles/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{N} synthetic stereo 512x512 uint8 tiles -> image decode -> InverseMelScale SGD-200 -> Griffin-Lim 64 "
+                               "-> int16 PCM (BASELINE.json configs[3]), sharded over the ranks with shard_range, PCM all_gathered over "
+                               "RCCL and copied to the host (the product entry point returns numpy)",
+                   "global_batch": N, "clips_per_gpu": -(-N // world), "griffin_lim_iters": 64,
+                   "parallelism": f"clips sharded over {world} GPU(s); one all_gather of {N * HOP * (N_FRAMES - 1) * 4 / 1e6:.0f} MB int16 PCM"},
+        "audio_sec_per_sec": round(tiles_per_s * HOP * (N_FRAMES - 1) / SR, 1),
+    }
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_distributed(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -251,8 +364,25 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if distributed else 0)
     torch.cuda.set_device(dev)
+    n_ranks = 1
+    if distributed:  # n_gpus = ranks that answered an RCCL all_reduce
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        n_ranks = int(ones.item())
+        assert n_ranks == world
+
+    def finish(out):
+        if rank == 0 and out is not None:
+            out["n_gpus"] = n_ranks
+            print(json.dumps(out), flush=True)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+
     if args.workload == "forward":
-        return forward_main(args, world, rank, dev, distributed)
+        return finish(forward_measure(args, world, rank, dev, distributed, world == 1 and not args.no_cpu_baseline))
+    if args.workload == "decode-stereo64":
+        return finish(stereo64_main(args, world, rank, dev, distributed))
 
     from riffusion import _hip
     from riffusion.spectrogram_params import SpectrogramParams
@@ -306,6 +436,7 @@ def main():
         alg_bytes = 20.0 * N_BINS * T * B
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         pmc = pmc_summary()
+        pmc_src = "profiles/gl_iter_pmc_latest.json"
         traffic = pmc.get("hbm_bytes_per_launch")
         roofline = {
             "kernel": "rfx::gl_iter_kernel<2>",
@@ -317,21 +448,31 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(avg_ms, 4),
-            # The figure above prices the kernel against the CANONICAL fused formulation of SURVEY 8(d)
-            # (|S| 4 B + tprev 8 B read + 8 B written per bin and iteration).  The shipped kernel applies the
-            # momentum in the time domain (STFT linearity) and streams only |S|: `traffic` (PMC) is what it
-            # really moves, and its binding resource is fp32 VALU issue, reported next.
+            "measured_in_this_run": ["avg_launch_ms", "achieved", "frac"],
+            # counters cannot be collected from inside the timed process: these fields are read from the committed
+            # rocprofv3 --pmc summary of the same kernel (re-collected whenever the kernel changes)
+            "from_profiles": {"fields": ["traffic", "actual_hbm_gbs", "actual_hbm_frac", "binding.wave_instructions_per_launch"],
+                              "source": pmc_src, "git": git_rev(pmc_src)},
+            # `achieved` prices the kernel against the CANONICAL fused formulation of SURVEY 8(d) (|S| 4 B + tprev
+            # 8 B read + 8 B written per bin and iteration: an HBM-bound kernel).  The shipped kernel applies the
+            # momentum in the time domain (STFT linearity), streams only |S| (`traffic` is what it really moves)
+            # and is bound by fp32 VALU issue: `binding` is the roofline that tracks progress from here.
             "formulation": "time-domain momentum: rebuilt - m*tprev = STFT(x_k - m*x_{k-1}); 4 B/bin/iteration streamed",
         }
         if traffic:
             roofline["actual_hbm_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
+            roofline["actual_hbm_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         valu = pmc.get("SQ_INSTS_VALU_per_launch")
         if valu:
-            # issue ceiling measured by tools/ubench/valu.hip: 1.13 ns per plain fp32 wave-instruction per SIMD, 1024 SIMDs
-            peak_ginstr = 1024 / 1.13
+            # spec issue rate (MI355X_MICROARCH.md): 1024 SIMD-32 units, a wave64 fp32 instruction every 2 cycles at 2.4 GHz
+            spec_ginstr = 1024 * 2.4 / 2
+            # sustained rate measured by tools/ubench/valu.hip (independent v_fma_f32, 8 waves per SIMD: the chip clocks
+            # down under full VALU load): 1.13 ns per wave-instruction per SIMD
+            sustained_ginstr = 1024 / 1.13
             got = valu / (avg_ms * 1e-3) / 1e9
-            roofline["valu_issue"] = {"wave_instructions_per_launch": valu, "achieved_ginstr_s": round(got, 1),
-                                      "peak_ginstr_s": round(peak_ginstr, 1), "frac": round(got / peak_ginstr, 4)}
+            roofline["binding"] = {"bound": "valu", "unit": "G wave-instructions/s", "wave_instructions_per_launch": valu,
+                                   "achieved": round(got, 1), "peak": round(spec_ginstr, 1), "frac": round(got / spec_ginstr, 4),
+                                   "sustained_peak": round(sustained_ginstr, 1), "frac_of_sustained": round(got / sustained_ginstr, 4)}
         # stage split of one step (events through torch on the current stream = the launch stream)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         evs[0].record()
@@ -350,12 +491,13 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     tiles_per_s = world * B * args.steps / elapsed
+    out = None
     if rank == 0:
         out = {
             "metric": "spectrogram_tiles_per_sec_griffinlim32" if args.iters == 32 else f"spectrogram_tiles_per_sec_griffinlim{args.iters}",
             "value": round(tiles_per_s, 2),
             "unit": "tiles/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -376,12 +518,16 @@ def main():
             "roofline": roofline,
             "stages": extra,
         }
+    # ---- configs[2] (audio -> mel image) measured in the same run and carried on the same line
+    fwd = None
+    if not args.no_forward:
+        fwd = forward_measure(args, world, rank, dev, distributed, with_cpu=False)
+    if rank == 0:
+        if fwd is not None:
+            out["forward"] = {k: fwd[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "stages")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.iters)
-        print(json.dumps(out), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(out if rank == 0 else None)
 
 
 if __name__ == "__main__":

@@ -106,6 +106,12 @@ struct rfx_plan {
   ImelTables imel{};
   void* d_imel_blob = nullptr;
   int* d_bin_pos = nullptr;        // [n_stft] primary slot position, [n_stft] duplicate (-1)
+  // fused forward path (banded mel projection inside the STFT kernel), valid when fwd_ok
+  bool fwd_ok = false;
+  float* d_band_wt = nullptr;      // [band_rows][Mpad]
+  int* d_band_lo = nullptr;        // [Mpad] followed by band_len [Mpad]
+  int band_rows = 0, Mpad = 0;
+  bool fwd_unfused = false;        // debugging override (RFX_FWD_UNFUSED), read once at creation
 };
 
 namespace rfx {
@@ -298,6 +304,28 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     }
     pl->imel_ok = ok;
     pl->imel_why = why;
+    // ---- fused forward path: per-filter band tables, weights transposed so that lane m reads row i coalesced
+    if (ok && M <= 2 * kThreads && (size_t)(f_hi - f_lo) * sizeof(float) <= (size_t)kCubeElems * sizeof(cf)) {
+      const int Mpad = (M + 63) / 64 * 64;
+      int rows = 1;
+      for (int m = 0; m < M; ++m) rows = band_hi[m] - band_lo[m] > rows ? band_hi[m] - band_lo[m] : rows;
+      rows = (rows + 7) / 8 * 8;  // the kernel reads eight rows per step
+      std::vector<float> wt((size_t)rows * Mpad, 0.f);
+      std::vector<int> lo_len(2 * (size_t)Mpad, 0);
+      for (int m = 0; m < M; ++m) {
+        lo_len[m] = band_lo[m];
+        lo_len[Mpad + m] = band_hi[m] - band_lo[m];
+        for (int f = band_lo[m]; f < band_hi[m]; ++f) wt[(size_t)(f - band_lo[m]) * Mpad + m] = h_melfb[(size_t)f * M + m];
+      }
+      RFX_HIP(hipMalloc(&pl->d_band_wt, wt.size() * sizeof(float)));
+      RFX_HIP(hipMemcpy(pl->d_band_wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+      RFX_HIP(hipMalloc(&pl->d_band_lo, lo_len.size() * sizeof(int)));
+      RFX_HIP(hipMemcpy(pl->d_band_lo, lo_len.data(), lo_len.size() * sizeof(int), hipMemcpyHostToDevice));
+      pl->band_rows = rows;
+      pl->Mpad = Mpad;
+      pl->fwd_ok = true;
+      pl->fwd_unfused = getenv("RFX_FWD_UNFUSED") != nullptr;
+    }
     if (ok) {
       // one device blob: csr_w | csr_ptr | band_lo | bin_m0 | bin_w0 | bin_w1 | bin_pos | bin_pos2
       const size_t nnz = csr_w.size();
@@ -350,6 +378,8 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_melfb_slots);
     (void)hipFree(plan->d_kblocks);
     (void)hipFree(plan->d_imel_blob);
+    (void)hipFree(plan->d_band_wt);
+    (void)hipFree(plan->d_band_lo);
   }
   delete plan;
   return RFX_OK;
@@ -528,6 +558,7 @@ int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int
 
 size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw) {
   if (!plan || B <= 0 || Lw <= kNfft / 2) return 0;
+  if (plan->fwd_ok && !plan->fwd_unfused) return 256;  // the fused kernel keeps the magnitudes on chip
   const size_t T = 1 + Lw / kHop;
   return align_up((size_t)B * T * kFrameStride * sizeof(float), 256);
 }
@@ -539,6 +570,29 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
   if (workspace_bytes < rfx_mel_workspace_bytes(plan, B, Lw) || Lw <= kNfft / 2)
     return fail(Lw <= kNfft / 2 ? RFX_ERR_INVALID : RFX_ERR_WORKSPACE, "rfx_mel_from_waveform: input too short or workspace too small");
   RFX_ON_DEVICE(plan->device);
+  if (plan->fwd_ok && !plan->fwd_unfused) {
+    StftMelArgs f;
+    f.wave = d_wave;
+    f.mel = d_mel_out;
+    f.tw1 = plan->d_tw1;
+    f.tw2 = plan->d_tw2;
+    f.win = plan->d_win;
+    f.band_wt = plan->d_band_wt;
+    f.band_lo = plan->d_band_lo;
+    f.band_len = plan->d_band_lo + plan->Mpad;
+    f.B = B;
+    f.Lw = Lw;
+    f.T = 1 + Lw / kHop;
+    f.M = plan->p.n_mels;
+    f.Mpad = plan->Mpad;
+    f.f_lo = plan->imel.f_lo;
+    f.f_hi = plan->imel.f_hi;
+    const long long frames = (long long)B * f.T;
+    int fpb = (int)((frames + 2LL * plan->num_cus - 1) / (2LL * plan->num_cus));
+    f.frames_per_block = fpb < 1 ? 1 : fpb > 16 ? 16 : fpb;
+    RFX_HIP(launch_stft_mel(f, (hipStream_t)stream));
+    return RFX_OK;
+  }
   float* mag = (float*)d_workspace;
   int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
   if (rc) return rc;

@@ -48,6 +48,23 @@ struct StftArgs {
 };
 hipError_t launch_stft(const StftArgs& a, hipStream_t stream);
 
+// fused forward path: waveform -> framed transform -> |X| -> banded mel projection, nothing but the (B, M, T) mel
+// amplitudes leaves the chip.  Valid for banded filterbanks (every filter's support one contiguous run of bins).
+struct StftMelArgs {
+  const float* wave;     // [B][Lw]
+  float* mel;            // [B][M][T]
+  const cf* tw1;
+  const cf* tw2;
+  const float* win;
+  const float* band_wt;  // [band_rows][Mpad]: weight of filter m on its i-th bin (band_lo[m] + i), zero past its end
+  const int* band_lo;    // [Mpad] first bin of filter m's band (padding filters: 0)
+  const int* band_len;   // [Mpad] bins in filter m's band (padding filters: 0)
+  int B, T, Lw, frames_per_block;
+  int M, Mpad;           // Mpad = M rounded up to 64
+  int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
+};
+hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream);
+
 // mel projection GEMM: out[b][m][t] = sum_p fbs[p][m] * mag[b*T+t][p]
 struct MelArgs {
   const float* mag;     // [N][kFrameStride]

@@ -147,8 +147,93 @@ __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
   }
 }
 
+// ---- fused forward path (replaces Spectrogram(power=None) -> abs -> MelScale, spectrogram_converter.py:165-185):
+// the frame engine as above; the magnitudes of the frame are then parked in LDS in BIN order (the cube is free once
+// P3 has read it) and every thread forms the mel amplitudes of one or two filters as the banded dot product
+//     mel[m] = sum_{i < band_len[m]} fb[band_lo[m] + i][m] * |X[band_lo[m] + i]|
+// i.e. the reference's `|X|^T @ fb` with the structural zeros of the triangular filterbank left out (7 976 of its
+// 4.5 M products for the default bank), summed in increasing bin order.  The 1.2 GB magnitude stream and the dense
+// GEMM of the unfused path disappear; only (B, M, T) floats are written.
+__global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ThreadId t = thread_id();
+  const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
+  const float* __restrict__ winp = a.win + t.npr;
+  float* magb = reinterpret_cast<float*>(smem);  // [f_hi - f_lo] magnitudes in bin order, aliases the cube
+  __syncthreads();
+
+  const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  const int clip = blockIdx.x / chunks;
+  const int f0 = (blockIdx.x - clip * chunks) * a.frames_per_block;
+  const int f1 = min(a.T, f0 + a.frames_per_block);
+  const float* __restrict__ x = a.wave + (size_t)clip * a.Lw;
+
+  // the (up to two) filters of this thread: m0 = threadIdx, m1 = threadIdx + 448; waves walk bands of similar length
+  const int m0 = threadIdx.x, m1 = threadIdx.x + kThreads;
+  const bool has0 = m0 < a.M, has1 = m1 < a.M;
+  const int lo0 = has0 ? a.band_lo[m0] - a.f_lo : 0, n0 = has0 ? a.band_len[m0] : 0;
+  const int lo1 = has1 ? a.band_lo[m1] - a.f_lo : 0, n1 = has1 ? a.band_len[m1] : 0;
+  const int nb = a.f_hi - a.f_lo;
+  float w10[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w10[j] = winp[j * kHop];
+
+  for (int fr = f0; fr < f1; ++fr) {
+    float u[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int p = reflect_index((fr + j - kHalfHops) * kHop + t.npr, a.Lw);
+      u[j] = x[p] * w10[j];
+    }
+    cf R[21];
+    frame_forward(u, R, f, t, [] {});
+    __syncthreads();  // every wave is done reading the cube: its memory now holds the magnitudes in bin order
+    if (t.active) {
+#pragma unroll
+      for (int kb = 0; kb < 21; ++kb) {
+        const int k = t.k1 + 40 * (t.idx + 21 * kb);
+        const int bin = k > kNfft / 2 ? kNfft - k : k;
+        // a bin stored twice (k mod 40 in {0, 20}) is written by its primary slot only
+        const bool primary = k <= kNfft / 2 || (t.k1 != 0 && t.k1 != 20);
+        if (primary && bin >= a.f_lo && bin < a.f_hi)
+          magb[bin - a.f_lo] = sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
+      }
+    }
+    __syncthreads();
+    {
+      // eight weights / magnitudes in flight per step (the table is zero-padded to a multiple of eight rows and the
+      // magnitude index is clamped, so the tail multiplies finite values by zero); bins are summed in increasing order
+      auto band_dot = [&](int m, int lo, int n) {
+        const float* __restrict__ wt = a.band_wt + m;
+        float s = 0.f;
+        for (int i = 0; i < n; i += 8) {
+          float w[8], v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[j] = wt[(size_t)(i + j) * a.Mpad];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = magb[min(lo + i + j, nb - 1)];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s = fmaf(w[j], v[j], s);
+        }
+        return s;
+      };
+      if (has0) a.mel[((size_t)clip * a.M + m0) * a.T + fr] = band_dot(m0, lo0, n0);
+      if (has1) a.mel[((size_t)clip * a.M + m1) * a.T + fr] = band_dot(m1, lo1, n1);  // first waves only (M <= 896)
+    }
+    __syncthreads();  // the next frame's P1 overwrites the magnitudes
+  }
+}
+
+hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream) {
+  const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  hipLaunchKernelGGL(stft_mel_kernel, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t prepare_frame_kernels() {
-  const hipError_t e = hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+  hipError_t e = hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
   return e != hipSuccess ? e : prepare_gl_kernels();
 }
 

@@ -36,3 +36,22 @@ def gather_clips(local: torch.Tensor, n_items: int, group: T.Optional[T.Any] = N
     dist.all_gather(parts, raw, group=group)
     parts = [p.view(local.dtype).reshape(pad.shape) for p in parts]
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def sharded_map(
+    convert: T.Callable[[int, int], torch.Tensor], n_items: int, group: T.Any = None
+) -> torch.Tensor:
+    """
+    The multi-GPU form of a batch call: rank r runs `convert(lo, hi)` on its slice [lo, hi) of the
+    clips (it must return a tensor with hi - lo rows, also when the slice is empty) and the per-rank
+    results are all_gathered into the full batch on every rank.  `group=None` runs the whole batch
+    locally (no process group needed); `group=True` means the default group.
+    """
+    if group is None:
+        return convert(0, n_items)
+    pg = None if group is True else group
+    lo, hi = shard_range(n_items, dist.get_world_size(pg), dist.get_rank(pg))
+    local = convert(lo, hi)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"convert({lo}, {hi}) returned {local.shape[0]} rows")
+    return gather_clips(local, n_items, pg)

@@ -5,8 +5,10 @@ Same sub-commands and keyword flags as the part of the reference CLI that drives
 (`riffusion/cli.py:23-95` audio-to-image / image-to-audio / print-exif, `:134-204`
 audio-to-images-batch), but the batch commands feed whole batches to the GPU
 (`SpectrogramImageConverter.spectrogram_images_from_waveforms` /
-`audio_from_spectrogram_images`) instead of one clip per thread-pool task.  argparse replaces argh
-(not installed here); without pydub only 16-bit PCM wav files are read and written.
+`audio_from_spectrogram_images`) instead of one clip per thread-pool task, and split the file list
+over the ranks when launched one process per GPU (`python -m torch.distributed.run
+--nproc-per-node 8 -m riffusion.cli images-to-audio-batch ...`).  argparse replaces argh (not
+installed here); without pydub only 16-bit PCM wav files are read and only wav is written.
 
     python -m riffusion.cli image-to-audio --image tile.png --audio out.wav
     python -m riffusion.cli audio-to-image --audio clip.wav --image tile.png
@@ -75,10 +77,34 @@ def print_exif(*, image: str) -> None:
         print(f"{name:<20} = {value:>15}")
 
 
-def images_to_audio_batch(*, image_dir: str, output_dir: str, batch_size: int = 64, device: str = "cuda") -> None:
-    """Decode every *.png of a directory, `batch_size` same-width tiles per GPU call."""
+def _rank_slice(items: T.Sequence[T.Any]) -> T.Sequence[T.Any]:
+    """Under `torchrun` / `torch.distributed.run` (one process per GPU) every rank converts its contiguous share of
+    the files and writes its own outputs: the N-GPU form of the reference's per-file thread pool (cli.py:172-204).
+    No process group is needed - files are independent and nothing is gathered."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world <= 1:
+        return items
+    from riffusion.batch_shard import shard_range
+
+    lo, hi = shard_range(len(items), world, rank)
+    return items[lo:hi]
+
+
+def _rank_device(device: str) -> str:
+    """'cuda' -> this rank's GPU when launched one process per GPU."""
+    if device == "cuda" and "LOCAL_RANK" in os.environ:
+        return f"cuda:{int(os.environ['LOCAL_RANK'])}"
+    return device
+
+
+def images_to_audio_batch(*, image_dir: str, output_dir: str, batch_size: int = 64, no_filters: bool = False,
+                          device: str = "cuda") -> None:
+    """Decode every *.png of a directory, `batch_size` same-width tiles per GPU call.  Each clip then gets the same
+    post-processing as `image-to-audio` (audio_util.apply_filters, reference spectrogram_image_converter.py:65-91)
+    unless --no-filters is given."""
     os.makedirs(output_dir, exist_ok=True)
-    paths = sorted(glob.glob(os.path.join(image_dir, "*.png")))
+    device = _rank_device(device)
+    paths = _rank_slice(sorted(glob.glob(os.path.join(image_dir, "*.png"))))
     groups: T.Dict[T.Tuple[SpectrogramParams, T.Tuple[int, int]], T.List[str]] = {}
     for path in paths:
         with Image.open(path) as im:
@@ -87,30 +113,54 @@ def images_to_audio_batch(*, image_dir: str, output_dir: str, batch_size: int = 
         converter = SpectrogramImageConverter(params=params, device=device)
         for i in range(0, len(members), batch_size):
             chunk = members[i : i + batch_size]
-            tiles = np.stack([image_util.rgb_array_from_image(Image.open(p)) for p in chunk])
-            pcm = converter.audio_from_spectrogram_images(tiles)
+            tiles = []
+            for p in chunk:
+                with Image.open(p) as im:
+                    tiles.append(image_util.rgb_array_from_image(im))
+            pcm = converter.audio_from_spectrogram_images(np.stack(tiles))
             for path, samples in zip(chunk, pcm):
+                segment = audio_util.PcmSegment(samples, params.sample_rate)
+                if not no_filters:
+                    segment = audio_util.apply_filters(segment, compression=False)
                 out = os.path.join(output_dir, os.path.splitext(os.path.basename(path))[0] + ".wav")
-                audio_util.PcmSegment(samples, params.sample_rate).export(out, format="wav")
+                segment.export(out, format="wav")
             print(f"Wrote {len(chunk)} clips to {output_dir}")
 
 
-def audio_to_images_batch(*, audio_dir: str, output_dir: str, stereo: bool = False, batch_size: int = 64,
-                          device: str = "cuda") -> None:
-    """Encode every *.wav of a directory (reference cli.py:134-204), same-length clips batched per GPU call."""
+def audio_to_images_batch(*, audio_dir: str, output_dir: str, image_extension: str = "jpg", step_size_ms: int = 10,
+                          num_frequencies: int = 512, min_frequency: int = 0, max_frequency: int = 10000,
+                          power_for_image: float = 0.25, mono: bool = False, sample_rate: int = 44100, device: str = "cuda",
+                          num_threads: int = 0, limit: int = -1, batch_size: int = 64) -> None:
+    """Process audio clips into spectrogram images in batch (reference cli.py:134-204, same flags and defaults: stereo
+    tiles unless --mono, files resampled to --sample-rate, unreadable files skipped, jpg output).  Instead of one clip
+    per thread-pool task (`num_threads` is accepted and ignored) same-length clips go to the GPU `batch_size` at a time."""
     import torch
 
     os.makedirs(output_dir, exist_ok=True)
-    paths = sorted(glob.glob(os.path.join(audio_dir, "*.wav")))
-    loaded: T.Dict[T.Tuple[int, int], T.List[T.Tuple[str, np.ndarray]]] = {}
-    channels = 2 if stereo else 1
+    device = _rank_device(device)
+    image_format = {"jpg": "JPEG", "jpeg": "JPEG", "png": "PNG"}[image_extension]
+    paths = sorted(p for p in glob.glob(os.path.join(audio_dir, "*")) if os.path.isfile(p))
+    if limit > 0:
+        paths = paths[:limit]
+    paths = _rank_slice(paths)
+    params = SpectrogramParams(step_size_ms=step_size_ms, num_frequencies=num_frequencies, min_frequency=min_frequency,
+                               max_frequency=max_frequency, power_for_image=power_for_image, stereo=not mono,
+                               sample_rate=sample_rate)
+    converter = SpectrogramImageConverter(params=params, device=device)
+    channels = 1 if mono else 2
+    loaded: T.Dict[int, T.List[T.Tuple[str, np.ndarray]]] = {}
     for path in paths:
-        seg = _load_segment(path).set_channels(channels)
+        try:
+            seg = _load_segment(path)
+        except Exception:  # the reference skips files it cannot read (cli.py:176-179)
+            continue
+        if seg.channels != channels:
+            seg = seg.set_channels(channels)
+        if seg.frame_rate != params.sample_rate:
+            seg = seg.set_frame_rate(params.sample_rate)
         wave = np.array([c.get_array_of_samples() for c in seg.split_to_mono()]).astype(np.float32)
-        loaded.setdefault((seg.frame_rate, wave.shape[1]), []).append((path, wave))
-    for (rate, _n), members in loaded.items():
-        params = SpectrogramParams(sample_rate=rate, stereo=stereo)
-        converter = SpectrogramImageConverter(params=params, device=device)
+        loaded.setdefault(wave.shape[1], []).append((path, wave))
+    for _n, members in loaded.items():
         for i in range(0, len(members), batch_size):
             chunk = members[i : i + batch_size]
             images, max_values = converter.spectrogram_images_from_waveforms(torch.from_numpy(np.stack([w for _, w in chunk])))
@@ -118,8 +168,8 @@ def audio_to_images_batch(*, audio_dir: str, output_dir: str, stereo: bool = Fal
                 exif_data = params.to_exif()
                 exif_data[SpectrogramParams.ExifTags.MAX_VALUE.value] = float(mx)
                 image.getexif().update(exif_data.items())
-                out = os.path.join(output_dir, os.path.splitext(os.path.basename(path))[0] + ".png")
-                image.save(out, exif=image.getexif(), format="PNG")
+                out = os.path.join(output_dir, os.path.splitext(os.path.basename(path))[0] + "." + image_extension)
+                image.save(out, exif=image.getexif(), format=image_format)
             print(f"Wrote {len(chunk)} images to {output_dir}")
 
 

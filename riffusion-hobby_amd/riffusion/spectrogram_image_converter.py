@@ -4,7 +4,10 @@ Spectrogram images <-> audio segments.
 Drop-in for the reference's `riffusion/spectrogram_image_converter.py:10-91` (same constructor,
 attributes and the two per-clip methods) plus batch entry points that keep many tiles in flight on
 the GPU: `audio_from_spectrogram_images` takes uint8 tiles in and hands int16 PCM out with one H2D
-and one D2H copy per batch.
+and one D2H copy per batch, takes the diffusion pipeline's output tensors directly
+(`riffusion_pipeline.py:427-434`), and shards a batch of clips over the ranks of a
+`torch.distributed` process group (one process per GPU; clips are independent, so the only
+collective is the final all_gather of the int16 PCM).
 """
 import typing as T
 
@@ -77,23 +80,66 @@ class SpectrogramImageConverter:
         img_np, mx_np = img.cpu().numpy(), mx.cpu().numpy()
         return [Image.fromarray(a, mode="RGB") for a in img_np], mx_np
 
+    @staticmethod
+    def quantize_pipeline_images(images: torch.Tensor) -> torch.Tensor:
+        """
+        The diffusion pipeline's hand-off (`riffusion_pipeline.py:427-434`): the VAE output is moved to
+        [0, 1] and NHWC float32 (`(image / 2 + 0.5).clamp(0, 1)`, `.permute(0, 2, 3, 1)`), then
+        `numpy_to_pil` quantises it with `(images * 255).round().astype("uint8")`.  This does that
+        quantisation on whatever device the tensor lives on (round-half-to-even like numpy, float32
+        like the reference), so the decoder can take the tensor without the `.cpu()` -> PIL -> numpy
+        -> `.to(device)` round trip.  (N, H, W, 3) float in [0, 1] -> (N, H, W, 3) uint8.
+        """
+        if images.dim() != 4 or images.shape[-1] != 3:
+            raise ValueError("expected (N, H, W, 3) images, channels last, as riffusion_pipeline.py:431 produces them")
+        return (images.to(torch.float32) * 255).round().to(torch.uint8)
+
     def audio_from_spectrogram_images(
         self,
         images_u8: T.Union[np.ndarray, torch.Tensor],
         max_value: float = 30e6,
         seed: T.Optional[int] = None,
         return_waveform: bool = False,
+        group: T.Any = None,
+        tiles_per_call: int = 64,
     ) -> np.ndarray:
-        """(N, H, W, 3) uint8 RGB tiles -> (N, samples, C) int16 PCM (or the float waveforms)."""
+        """
+        (N, H, W, 3) RGB tiles -> (N, samples, C) int16 PCM (or the float waveforms).
+
+        `images_u8` is a uint8 array / tensor on any device, or the diffusion pipeline's float [0, 1]
+        NHWC tensor (quantised here like `numpy_to_pil`, see `quantize_pipeline_images`).
+
+        `group`: a `torch.distributed` process group (or True for the default group).  Every rank
+        passes the SAME full batch; rank r converts clips `shard_range(N, world, r)` on its own GPU and
+        the int16 PCM is all_gathered, so every rank returns the full (N, samples, C) result.  A clip's
+        channels never leave their rank (they share the SGD loss mean and the peak normalisation).
+        Like the reference, the two random initialisations are not reproducible across different
+        shardings (each call draws its own streams from `seed`).
+        """
+        from riffusion import batch_shard
+
         conv = self.converter
         plan = conv._plan()
         imgs = torch.as_tensor(np.ascontiguousarray(images_u8) if isinstance(images_u8, np.ndarray) else images_u8)
-        imgs = imgs.to(conv.device)
+        if imgs.is_floating_point():
+            imgs = self.quantize_pipeline_images(imgs)
+        n_total = imgs.shape[0]
         C = 2 if self.p.stereo else 1
-        lut = torch.from_numpy(image_util.decode_lut(float(self.p.power_for_image), float(max_value))).to(conv.device)
-        mel = plan.image_decode(imgs, self.p.stereo, lut)
-        wave = conv.waveform_from_mel_amplitudes(mel, seed=seed, channels_per_clip=C)
-        if return_waveform:
-            return wave.reshape(imgs.shape[0], C, -1).cpu().numpy()
-        pcm, _ = plan.pcm16(wave, channels=C, normalize=True)
-        return pcm.cpu().numpy()
+        base_seed = conv._seed(seed)
+        lut = torch.from_numpy(image_util.decode_lut(float(self.p.power_for_image), float(max_value))).to(plan.device)
+
+        def convert(lo: int, hi: int) -> torch.Tensor:
+            outs = []
+            for a in range(lo, hi, tiles_per_call):  # bounded working set: |S| alone is 19 MB per tile-channel
+                b = min(hi, a + tiles_per_call)
+                mel = plan.image_decode(imgs[a:b].to(plan.device), self.p.stereo, lut)
+                wave = conv.waveform_from_mel_amplitudes(mel, seed=base_seed + 2 * a, channels_per_clip=C)
+                outs.append(wave.reshape(b - a, C, -1) if return_waveform else plan.pcm16(wave, channels=C, normalize=True)[0])
+            if outs:
+                return torch.cat(outs, dim=0)
+            L = self.p.hop_length * (imgs.shape[2] - 1)  # a rank with an empty shard still joins the gather
+            return torch.empty((0, C, L) if return_waveform else (0, L, C),
+                               dtype=torch.float32 if return_waveform else torch.int16, device=plan.device)
+
+        local = batch_shard.sharded_map(convert, n_total, group)
+        return local.cpu().numpy()

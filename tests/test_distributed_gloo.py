@@ -45,3 +45,39 @@ def test_two_rank_gather(n_items):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, n_items), nprocs=2, join=True)
+
+
+def _map_worker(rank, world, port, n_items):
+    from riffusion.batch_shard import sharded_map
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def convert(lo, hi):  # stand-in for "decode clips lo..hi on this rank's GPU": (hi - lo, 4, 1) int16 PCM
+        calls.append((lo, hi))
+        return torch.arange(lo, hi, dtype=torch.int16).reshape(-1, 1, 1).repeat(1, 4, 1)
+
+    full = sharded_map(convert, n_items, dist.group.WORLD)
+    assert calls == [shard_range(n_items, world, rank)]  # each rank converts only its own slice, once
+    assert full.shape == (n_items, 4, 1) and torch.equal(full[:, 0, 0], torch.arange(n_items, dtype=torch.int16))
+    assert torch.equal(sharded_map(convert, n_items, True), full)  # True = default group
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [1, 7])
+def test_sharded_map_two_ranks(n_items):
+    """The sharding used by SpectrogramImageConverter.audio_from_spectrogram_images(group=...) and bench.py's
+    decode-stereo64 workload: world_size 2 over gloo, including a rank with an empty shard (n_items = 1)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_map_worker, args=(2, port, n_items), nprocs=2, join=True)
+
+
+def test_sharded_map_without_group_runs_locally():
+    from riffusion.batch_shard import sharded_map
+
+    out = sharded_map(lambda lo, hi: torch.arange(lo, hi)[:, None], 5, None)
+    assert out.shape == (5, 1)

@@ -47,6 +47,19 @@ def test_mel_amplitudes_match_oracle(plan, params, O, length, batch):
     assert torch.linalg.norm(got - ref) / torch.linalg.norm(ref) <= 1e-4
 
 
+def test_fused_forward_equals_stft_then_mfma_melscale(plan, params, O):
+    """`mel_from_waveform` runs the fused kernel (framed transform -> |X| -> banded projection on chip); the standalone
+    members Spectrogram -> abs -> MelScale (MFMA GEMM over all slot positions) must give the same amplitudes."""
+    wave = synthetic_wave(3, 441 * 200 + 17, seed=9)
+    fused = plan.mel_from_waveform(wave.cuda())
+    mag, _, Tn = plan.stft(wave.cuda(), want_mag=True, want_spec=False)
+    dense = plan.mel_scale(plan.unpack_magnitudes(mag, 3, Tn))
+    assert fused.shape == dense.shape == (3, 512, Tn)
+    assert float((fused - dense).abs().max() / dense.abs().max()) <= 2e-6
+    ref = O.mel_amplitudes_from_waveform(wave, O.params_from(params))
+    assert torch.linalg.norm(fused.cpu() - ref) / torch.linalg.norm(ref) <= 1e-4
+
+
 def test_mel_other_frequency_range(O):
     """20 Hz .. 20 kHz parameters of the reference's own round-trip test (spectrogram_converter_test.py:46-53)."""
     from riffusion import _hip

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 import warnings
 
 import numpy as np
@@ -241,3 +242,142 @@ def test_header_is_plain_c_and_links_from_c(repo_root, tmp_path):
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(maxsplit=4)
     assert out[:3] == ["1", "9408", "8821"]
     assert int(out[3]) < 0 and "rfx_plan_create" in out[4]
+
+
+# ---- segment arithmetic pinned on CPython's audioop (the C module pydub.AudioSegment itself calls) ----------------
+try:
+    import audioop as _ao
+except ImportError:  # Python >= 3.13
+    _ao = None
+
+
+@pytest.mark.skipif(_ao is None, reason="audioop removed from this interpreter")
+def test_numpy_restatements_equal_audioop_bit_for_bit():
+    """PcmSegment runs on audioop when it exists; its numpy fall-backs (interpreters without audioop) are pinned here."""
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((20000, 2)) * 9000).clip(-32768, 32767).astype(np.int16)
+    x[:4] = [[32767, -32768], [-32768, 32767], [1, -1], [0, 0]]
+    for fac in (0.0, 0.001, 0.25, 0.5, 0.7071, 1.0, 1.9999, 2.2387211385683394, 10.0, 1e6):
+        want = np.frombuffer(_ao.mul(x.tobytes(), 2, fac), dtype=np.int16).reshape(x.shape)
+        assert np.array_equal(audio_util.PcmSegment._mul_np(x, fac), want), fac
+    assert np.array_equal(audio_util.PcmSegment._tomono_np(x), np.frombuffer(_ao.tomono(x.tobytes(), 2, 0.5, 0.5), dtype=np.int16))
+    seg = audio_util.PcmSegment(x, 44100)
+    assert seg.rms == _ao.rms(x.tobytes(), 2) == int(np.sqrt(np.sum(x.astype(np.float64) ** 2) / x.size))
+    assert seg.max == _ao.max(x.tobytes(), 2) == 32768
+    st = audio_util.PcmSegment(x[:, :1].copy(), 44100).set_channels(2)
+    assert np.array_equal(st._data[:, 0], x[:, 0]) and np.array_equal(st._data[:, 1], x[:, 0])
+
+
+@pytest.mark.skipif(_ao is None, reason="audioop removed from this interpreter")
+def test_apply_filters_equals_pydub_call_sequence_on_audioop():
+    """Reference audio_util.py:64-70 written out as the audioop calls pydub 0.25.1 makes for it (apply_gain = audioop.mul by
+    10**(dB/20); dBFS = 20*log10(audioop.rms / 32768); normalize = gain by 20*log10(32768*10**(-0.1/20) / audioop.max))."""
+    import math
+
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((30000, 2)) * 2500).astype(np.int16)
+    raw = x.tobytes()
+    dbfs = 20 * math.log(_ao.rms(raw, 2) / 32768.0, 10)
+    raw = _ao.mul(raw, 2, 10 ** ((-12 - dbfs) / 20))
+    peak = _ao.max(raw, 2)
+    raw = _ao.mul(raw, 2, 10 ** ((20 * math.log(32768.0 * (10 ** (-0.1 / 20)) / peak, 10)) / 20))
+    got = audio_util.apply_filters(audio_util.PcmSegment(x, 44100), compression=False)
+    assert np.array_equal(got._data, np.frombuffer(raw, dtype=np.int16).reshape(-1, 2))
+
+
+def test_stitch_and_overlay_segments():
+    """Reference audio_util.py:75-100 without pydub: append with crossfade, overlay."""
+    rate = 8000
+    a = audio_util.PcmSegment(np.full((rate, 1), 1000, np.int16), rate)  # 1 s
+    b = audio_util.PcmSegment(np.full((rate // 2, 1), -3000, np.int16), rate)  # 0.5 s
+    out = audio_util.stitch_segments([a, b], crossfade_s=0.25)
+    n_x = rate // 4
+    assert out.frame_count() == a.frame_count() + b.frame_count() - n_x and out.frame_rate == rate
+    y = out.get_array_of_samples()
+    assert np.all(y[: rate - n_x] == 1000) and np.all(y[rate:] == -3000)  # untouched outside the crossfade
+    mid = y[rate - n_x : rate].astype(int)
+    assert mid[0] in (1000, 999) and abs(mid[-1] + 3000) <= 30  # a fades out, b fades in (coarse 1 ms gain steps)
+    assert np.all(np.diff(mid) <= 0)
+    assert audio_util.stitch_segments([a], 0.1) is a
+    with pytest.raises(ValueError):
+        audio_util.stitch_segments([a, b], crossfade_s=0.75)  # longer than the appended segment, as pydub raises
+    plain = a.append(b, crossfade=0)
+    assert plain.frame_count() == a.frame_count() + b.frame_count()
+    # overlay: saturating sum over the overlap, length of the first segment
+    loud = audio_util.PcmSegment(np.full((rate, 1), 30000, np.int16), rate)
+    ov = audio_util.overlay_segments([loud, loud, b])
+    z = ov.get_array_of_samples()
+    assert ov.frame_count() == rate and z[0] == 32767 - 3000 and z[-1] == 32767
+
+
+@pytest.mark.skipif(_ao is None, reason="audioop removed from this interpreter")
+def test_set_frame_rate_is_audioop_ratecv():
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal((4800, 2)) * 5000).astype(np.int16)
+    seg = audio_util.PcmSegment(x, 48000).set_frame_rate(44100)
+    want, _ = _ao.ratecv(x.tobytes(), 2, 2, 48000, 44100, None)
+    assert seg.frame_rate == 44100 and np.array_equal(seg._data, np.frombuffer(want, dtype=np.int16).reshape(-1, 2))
+    assert audio_util.PcmSegment(x, 44100).set_frame_rate(44100)._data is not None
+
+
+def test_cli_batch_flags_mirror_the_reference():
+    """reference cli.py:134-149: stereo tiles by default (--mono switches), --sample-rate, --image-extension jpg, --limit."""
+    from riffusion import cli
+
+    ns = cli.build_parser().parse_args(["audio-to-images-batch", "--audio-dir", "a", "--output-dir", "b"])
+    assert ns.mono is False and ns.sample_rate == 44100 and ns.image_extension == "jpg" and ns.limit == -1
+    assert ns.num_frequencies == 512 and ns.max_frequency == 10000 and ns.power_for_image == 0.25 and ns.step_size_ms == 10
+    ns = cli.build_parser().parse_args(["images-to-audio-batch", "--image-dir", "a", "--output-dir", "b", "--no-filters"])
+    assert ns.no_filters is True and ns.batch_size == 64
+    # file lists split over the ranks of a one-process-per-GPU launch
+    old = {k: os.environ.get(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        os.environ.update(WORLD_SIZE="4", RANK="1", LOCAL_RANK="1")
+        assert list(cli._rank_slice(list(range(10)))) == [3, 4, 5] and cli._rank_device("cuda") == "cuda:1"
+        assert cli._rank_device("cuda:3") == "cuda:3"
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert list(cli._rank_slice([1, 2, 3])) == [1, 2, 3]
+
+
+def test_quantize_pipeline_images_matches_numpy_to_pil():
+    """riffusion_pipeline.py:433-434 -> diffusers numpy_to_pil: (images * 255).round().astype('uint8')."""
+    from riffusion.spectrogram_image_converter import SpectrogramImageConverter as C
+
+    rng = np.random.default_rng(0)
+    x = rng.random((3, 16, 8, 3), dtype=np.float32)
+    x.reshape(-1)[:6] = [0.0, 1.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255]
+    want = (x * 255).round().astype("uint8")
+    got = C.quantize_pipeline_images(torch.from_numpy(x))
+    assert got.dtype == torch.uint8 and np.array_equal(got.numpy(), want)
+    with pytest.raises(ValueError):
+        C.quantize_pipeline_images(torch.zeros(1, 3, 8, 8))  # NCHW: not what the pipeline hands over
+
+
+def test_bench_gpus_flag_relaunches_n_ranks(repo_root, monkeypatch):
+    """bench.py --gpus N outside a distributed launch starts N ranks under torch.distributed.run on 127.0.0.1."""
+    import importlib
+    import subprocess
+
+    monkeypatch.syspath_prepend(repo_root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.relaunch_distributed(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # and main() takes that route only when no RANK is set
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(bench, "relaunch_distributed", lambda n: 17)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 17
