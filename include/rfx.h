@@ -35,16 +35,16 @@ typedef enum {
   RFX_ERR_INVALID = -1,     /* bad argument / unsupported geometry */
   RFX_ERR_HIP = -2,         /* a HIP runtime call failed */
   RFX_ERR_WORKSPACE = -3,   /* workspace too small */
-  RFX_ERR_UNSUPPORTED = -4  /* STFT geometry other than n_fft = 40 hop, win = 10 hop, hop = 441 */
+  RFX_ERR_UNSUPPORTED = -4  /* FFT length with a prime factor above 13 or beyond the LDS budget; non-banded filterbank */
 } rfx_status;
 
 /* Mirrors the fields of riffusion/spectrogram_params.py:21-42 that the arithmetic depends on,
  * already resolved to samples (spectrogram_params.py:62-81). */
 typedef struct {
   int32_t sample_rate;
-  int32_t n_fft;        /* 17640 */
-  int32_t win_length;   /* 4410  */
-  int32_t hop_length;   /* 441   */
+  int32_t n_fft;        /* 17640 at 44.1 kHz: that geometry (with win 4410, hop 441) runs on the specialised engine, */
+  int32_t win_length;   /* 4410     every other one (48 kHz: 19200 / 4800 / 480, 22.05 kHz: 8820 / 2205 / 220, ...) on */
+  int32_t hop_length;   /* 441      the generic Stockham engine: same entry points, same semantics, about 3x slower   */
   int32_t n_mels;       /* num_frequencies */
   int32_t max_mel_iters;
 } rfx_params;
@@ -52,8 +52,12 @@ typedef struct {
 const char* rfx_last_error(void);
 int rfx_version(void);
 /* number of elements (complex or float) between consecutive frames of a slot-major array */
-int rfx_frame_stride(void);
+int rfx_frame_stride(void);   /* of the default 44.1 kHz geometry; per plan: rfx_plan_frame_stride */
 int rfx_num_bins(void);
+/* frame stride of THIS plan's slot arrays (generic-geometry plans store plain bin-ordered frames, n_stft rounded up to 64) */
+int rfx_plan_frame_stride(const rfx_plan* plan);
+/* 1 when the plan runs on the generic engine (any geometry but 17640 / 4410 / 441) */
+int rfx_plan_is_generic(const rfx_plan* plan);
 
 /* Builds the device constants that spectrogram_converter.py:47-99 builds as torchaudio module
  * buffers: the periodic Hann window (h_window: win_length floats, as torch.hann_window gives it)
@@ -106,7 +110,8 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
 
 /* Standalone torchaudio.transforms.MelScale.forward (spectrogram_converter.py:185) for callers that hold linear
  * magnitudes in the reference's (B, n_stft, T) layout: packs them into slots and runs the same MFMA projection.
- * Workspace: rfx_frame_stride() * B * T floats. */
+ * Workspace: rfx_mel_scale_workspace_bytes. */
+size_t rfx_mel_scale_workspace_bytes(const rfx_plan* plan, int B, int T);
 int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_mel_out, void* d_workspace,
                   size_t workspace_bytes, void* stream);
 

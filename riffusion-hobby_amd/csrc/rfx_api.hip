@@ -112,6 +112,12 @@ struct rfx_plan {
   int* d_band_lo = nullptr;        // [Mpad] followed by band_len [Mpad]
   int band_rows = 0, Mpad = 0;
   bool fwd_unfused = false;        // debugging override (RFX_FWD_UNFUSED), read once at creation
+  // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
+  bool generic = false;
+  GenGeom gg{};
+  GenTables gt{};
+  void* d_gen_tables = nullptr;
+  int frame_stride = kFrameStride;
 };
 
 namespace rfx {
@@ -138,15 +144,38 @@ const char* rfx_last_error(void) { return g_err.c_str(); }
 int rfx_version(void) { return 1; }
 int rfx_frame_stride(void) { return kFrameStride; }
 int rfx_num_bins(void) { return kBins; }
+int rfx_plan_frame_stride(const rfx_plan* plan) { return plan ? plan->frame_stride : 0; }
+int rfx_plan_is_generic(const rfx_plan* plan) { return plan && plan->generic ? 1 : 0; }
 
 int rfx_plan_destroy(rfx_plan* plan);
 
 int rfx_plan_create(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
                     rfx_plan** out_plan) {
   if (!params || !out_plan || !h_window) return fail(RFX_ERR_INVALID, "rfx_plan_create: null argument");
-  if (params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop)
-    return fail(RFX_ERR_UNSUPPORTED,
-                "rfx_plan_create: only the 44.1 kHz geometry n_fft=17640 win=4410 hop=441 is implemented in HIP");
+  const bool generic = params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop ||
+                       getenv("RFX_FORCE_GENERIC") != nullptr;
+  GenGeom gg{};
+  if (generic) {
+    // any geometry torch.stft accepts (0 < hop, 0 < win <= n_fft) whose FFT length factors into the implemented radices
+    if (params->n_fft < 2 || params->hop_length < 1 || params->win_length < 1 || params->win_length > params->n_fft)
+      return fail(RFX_ERR_INVALID, "rfx_plan_create: need 0 < hop_length, 0 < win_length <= n_fft");
+    gg.n_fft = params->n_fft;
+    gg.win = params->win_length;
+    gg.hop = params->hop_length;
+    gg.n_stft = params->n_fft / 2 + 1;
+    gg.even = params->n_fft % 2 == 0;
+    gg.nc = gg.even ? params->n_fft / 2 : params->n_fft;
+    gg.left = (params->n_fft - params->win_length) / 2;
+    gg.fs = (gg.n_stft + 63) / 64 * 64;
+    gg.nhi = gg.nc / kGenTwLo + 1;
+    gg.nhi2 = gg.nc / kGenTwLo + 2;
+    if (gg.nc > kGenMaxNc)
+      return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: n_fft = " + std::to_string(params->n_fft) + " needs more than the 160 KiB of LDS a "
+                  "workgroup has for its two FFT buffers (supported: n_fft <= 20000 when even, <= 10000 when odd)");
+    if (!gen_factor(gg.nc, gg.radix, &gg.nstages))
+      return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: FFT length " + std::to_string(gg.nc) + " (from n_fft = " + std::to_string(params->n_fft) +
+                  ") has a prime factor above 13; implemented radices: 2, 3, 4, 5, 7, 11, 13");
+  }
   RFX_ON_DEVICE(device);
   rfx_plan* pl = new rfx_plan();
   struct Guard {  // releases the half-built plan if any step below fails
@@ -156,12 +185,17 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
   pl->p = *params;
   pl->device = device;
   pl->n_stft = params->n_fft / 2 + 1;
+  pl->generic = generic;
+  pl->gg = gg;
+  pl->frame_stride = generic ? gg.fs : kFrameStride;
+  const int F = pl->n_stft;  // linear bins
   hipDeviceProp_t prop;
   RFX_HIP(hipGetDeviceProperties(&prop, device));
   pl->num_cus = prop.multiProcessorCount;
   // per-device kernel attributes (dynamic LDS above 64 KB) and occupancy; environment knobs are read here,
   // once, never on the hot calls
   RFX_HIP(prepare_frame_kernels());
+  if (generic) RFX_HIP(prepare_generic_kernels(gg));
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
   if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
   pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : 0;
@@ -183,23 +217,47 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     }
   RFX_HIP(hipMalloc(&pl->d_tw1, tw1.size() * sizeof(cf)));
   RFX_HIP(hipMalloc(&pl->d_tw2, tw2.size() * sizeof(cf)));
-  RFX_HIP(hipMalloc(&pl->d_win, kWin * sizeof(float)));
+  RFX_HIP(hipMalloc(&pl->d_win, (size_t)params->win_length * sizeof(float)));
   RFX_HIP(hipMemcpy(pl->d_tw1, tw1.data(), tw1.size() * sizeof(cf), hipMemcpyHostToDevice));
   RFX_HIP(hipMemcpy(pl->d_tw2, tw2.data(), tw2.size() * sizeof(cf), hipMemcpyHostToDevice));
-  RFX_HIP(hipMemcpy(pl->d_win, h_window, kWin * sizeof(float), hipMemcpyHostToDevice));
+  RFX_HIP(hipMemcpy(pl->d_win, h_window, (size_t)params->win_length * sizeof(float), hipMemcpyHostToDevice));
+  if (generic) {
+    // two-level twiddle tables of the Stockham passes (base nc) and of the real <-> packed split (base n_fft)
+    std::vector<cf> t(2 * kGenTwLo + gg.nhi + gg.nhi2);
+    cf* lo = t.data();
+    cf* hi = lo + kGenTwLo;
+    cf* lo2 = hi + gg.nhi;
+    cf* hi2 = lo2 + kGenTwLo;
+    auto root = [&](long long num, long long den) {
+      const double a = -PI2 * (double)(num % den) / (double)den;
+      return cf{(float)cos(a), (float)sin(a)};
+    };
+    for (int i = 0; i < kGenTwLo; ++i) { lo[i] = root(i, gg.nc); lo2[i] = root(i, gg.n_fft); }
+    for (int i = 0; i < gg.nhi; ++i) hi[i] = root((long long)i * kGenTwLo, gg.nc);
+    for (int i = 0; i < gg.nhi2; ++i) hi2[i] = root((long long)i * kGenTwLo, gg.n_fft);
+    RFX_HIP(hipMalloc(&pl->d_gen_tables, t.size() * sizeof(cf)));
+    RFX_HIP(hipMemcpy(pl->d_gen_tables, t.data(), t.size() * sizeof(cf), hipMemcpyHostToDevice));
+    cf* d = (cf*)pl->d_gen_tables;
+    pl->gt.lo = d;
+    pl->gt.hi = d + kGenTwLo;
+    pl->gt.lo2 = d + kGenTwLo + gg.nhi;
+    pl->gt.hi2 = d + 2 * kGenTwLo + gg.nhi;
+    pl->gt.win = pl->d_win;
+  }
 
   if (h_melfb) {
     const int M = params->n_mels;
     if (M <= 0) return fail(RFX_ERR_INVALID, "rfx_plan_create: n_mels must be positive");
-    RFX_HIP(hipMalloc(&pl->d_melfb, (size_t)kBins * M * sizeof(float)));
-    RFX_HIP(hipMemcpy(pl->d_melfb, h_melfb, (size_t)kBins * M * sizeof(float), hipMemcpyHostToDevice));
+    RFX_HIP(hipMalloc(&pl->d_melfb, (size_t)F * M * sizeof(float)));
+    RFX_HIP(hipMemcpy(pl->d_melfb, h_melfb, (size_t)F * M * sizeof(float), hipMemcpyHostToDevice));
     // slot-ordered copy: row of slot position p = filterbank row of its bin for PRIMARY slots, zero for
     // the 440 duplicate slots and the 3 padding positions, so a GEMM over slot order equals the
     // reference's GEMM over bins up to summation order
     const int Mp = (M + 127) / 128 * 128;  // columns padded to the GEMM's 128-row tile: aligned, test-free loads
     pl->melfb_cols = Mp;
+    if (!generic) {
     std::vector<float> fbs((size_t)kFrameStride * Mp, 0.f);
-    std::vector<char> seen(kBins, 0);
+    std::vector<char> seen(F, 0);
     for (int k1 = 0; k1 < 21; ++k1)
       for (int ka = 0; ka < 21; ++ka)
         for (int kb = 0; kb < 21; ++kb) {
@@ -224,15 +282,16 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     pl->n_kblocks = (int)kb.size();
     RFX_HIP(hipMalloc(&pl->d_kblocks, (kb.size() + 1) * sizeof(int)));
     RFX_HIP(hipMemcpy(pl->d_kblocks, kb.data(), kb.size() * sizeof(int), hipMemcpyHostToDevice));
+    }  // !generic
 
     // ---- banded tables for InverseMelScale: every bin feeds at most two ADJACENT mel filters and
     // every filter's support is one contiguous run of bins (true for torchaudio's triangular banks)
-    std::vector<int> bin_m0(kBins, -1), band_lo(M, 0), band_hi(M, 0), csr_ptr(M + 1, 0);
-    std::vector<float> bin_w0(kBins, 0.f), bin_w1(kBins, 0.f), csr_w;
+    std::vector<int> bin_m0(F, -1), band_lo(M, 0), band_hi(M, 0), csr_ptr(M + 1, 0);
+    std::vector<float> bin_w0(F, 0.f), bin_w1(F, 0.f), csr_w;
     bool ok = true;
     std::string why;
-    int f_lo = kBins, f_hi = 0;
-    for (int f = 0; f < kBins && ok; ++f) {
+    int f_lo = F, f_hi = 0;
+    for (int f = 0; f < F && ok; ++f) {
       int first = -1, cnt = 0, last = -1;
       for (int m = 0; m < M; ++m)
         if (h_melfb[(size_t)f * M + m] != 0.f) { if (first < 0) first = m; last = m; ++cnt; }
@@ -246,9 +305,9 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     }
     for (int m = 0; m < M && ok; ++m) {
       int lo = -1, hi = -1;
-      for (int f = 0; f < kBins; ++f)
+      for (int f = 0; f < F; ++f)
         if (h_melfb[(size_t)f * M + m] != 0.f) { if (lo < 0) lo = f; hi = f + 1; }
-      if (lo < 0) { lo = hi = (f_lo < kBins ? f_lo : 0); }
+      if (lo < 0) { lo = hi = (f_lo < F ? f_lo : 0); }
       for (int f = lo; f < hi; ++f)
         if (h_melfb[(size_t)f * M + m] == 0.f) { ok = false; why = "a mel filter's support is not contiguous"; break; }
       band_lo[m] = lo;
@@ -260,7 +319,10 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     if (ok && (f_hi <= f_lo)) { ok = false; why = "empty filterbank"; }
     if (ok && (f_hi - f_lo > 36 * 256)) { ok = false; why = "more than 9216 active bins"; }
     if (ok && M > 1024) { ok = false; why = "more than 1024 mel filters"; }
-    std::vector<int> bin_pos(kBins, -1), bin_pos2(kBins, -1);
+    std::vector<int> bin_pos(F, -1), bin_pos2(F, -1);
+    if (generic)
+      for (int f = 0; f < F; ++f) bin_pos[f] = f;  // plain bin-ordered frames
+    else
     for (int k1 = 0; k1 < 21; ++k1)
       for (int ka = 0; ka < 21; ++ka)
         for (int kbq = 0; kbq < 21; ++kbq) {
@@ -272,7 +334,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     // group formulation (fast kernel): active bins contiguous with no zero row inside, first-filter index
     // non-decreasing, and the per-thread pairing (short group t, long group M-1-t) fits 8 + 24 registers
     std::vector<int> grp_start(M + 1, 0);
-    bool fast = ok && M <= 512, perwave = false;
+    bool fast = ok && M <= 512 && !generic, perwave = false;  // the group kernels are written for the slot layout
     if (fast) {
       int prev = 0;
       for (int f = f_lo; f < f_hi && fast; ++f) {
@@ -305,7 +367,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     pl->imel_ok = ok;
     pl->imel_why = why;
     // ---- fused forward path: per-filter band tables, weights transposed so that lane m reads row i coalesced
-    if (ok && M <= 2 * kThreads && (size_t)(f_hi - f_lo) * sizeof(float) <= (size_t)kCubeElems * sizeof(cf)) {
+    if (ok && (generic || (M <= 2 * kThreads && (size_t)(f_hi - f_lo) * sizeof(float) <= (size_t)kCubeElems * sizeof(cf)))) {
       const int Mpad = (M + 63) / 64 * 64;
       int rows = 1;
       for (int m = 0; m < M; ++m) rows = band_hi[m] - band_lo[m] > rows ? band_hi[m] - band_lo[m] : rows;
@@ -331,18 +393,18 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       const size_t nnz = csr_w.size();
       size_t off = 0;
       auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-      const size_t o_w = take(nnz * 4), o_ptr = take((M + 1) * 4), o_lo = take(M * 4), o_m0 = take(kBins * 4),
-                   o_w0 = take(kBins * 4), o_w1 = take(kBins * 4), o_p = take(kBins * 4), o_p2 = take(kBins * 4),
+      const size_t o_w = take(nnz * 4), o_ptr = take((M + 1) * 4), o_lo = take(M * 4), o_m0 = take(F * 4),
+                   o_w0 = take(F * 4), o_w1 = take(F * 4), o_p = take(F * 4), o_p2 = take(F * 4),
                    o_gs = take((M + 1) * 4);
       std::vector<char> blob(off);
       memcpy(&blob[o_w], csr_w.data(), nnz * 4);
       memcpy(&blob[o_ptr], csr_ptr.data(), (M + 1) * 4);
       memcpy(&blob[o_lo], band_lo.data(), M * 4);
-      memcpy(&blob[o_m0], bin_m0.data(), kBins * 4);
-      memcpy(&blob[o_w0], bin_w0.data(), kBins * 4);
-      memcpy(&blob[o_w1], bin_w1.data(), kBins * 4);
-      memcpy(&blob[o_p], bin_pos.data(), kBins * 4);
-      memcpy(&blob[o_p2], bin_pos2.data(), kBins * 4);
+      memcpy(&blob[o_m0], bin_m0.data(), F * 4);
+      memcpy(&blob[o_w0], bin_w0.data(), F * 4);
+      memcpy(&blob[o_w1], bin_w1.data(), F * 4);
+      memcpy(&blob[o_p], bin_pos.data(), F * 4);
+      memcpy(&blob[o_p2], bin_pos2.data(), F * 4);
       memcpy(&blob[o_gs], grp_start.data(), (M + 1) * 4);
       RFX_HIP(hipMalloc(&pl->d_imel_blob, off));
       RFX_HIP(hipMemcpy(pl->d_imel_blob, blob.data(), off, hipMemcpyHostToDevice));
@@ -380,6 +442,7 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_imel_blob);
     (void)hipFree(plan->d_band_wt);
     (void)hipFree(plan->d_band_lo);
+    (void)hipFree(plan->d_gen_tables);
   }
   delete plan;
   return RFX_OK;
@@ -388,19 +451,22 @@ int rfx_plan_destroy(rfx_plan* plan) {
 int rfx_pack_magnitudes(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_slots, void* stream) {
   if (!plan || !d_lin_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_pack_magnitudes: bad argument");
   RFX_ON_DEVICE(plan->device);
-  RFX_HIP(launch_pack_mag(d_lin_bft, d_slots, B, T, (hipStream_t)stream));
+  if (plan->generic) RFX_HIP(launch_gen_pack(d_lin_bft, d_slots, false, B, plan->n_stft, T, plan->gg.fs, (hipStream_t)stream));
+  else RFX_HIP(launch_pack_mag(d_lin_bft, d_slots, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
 int rfx_pack_complex(const rfx_plan* plan, const void* d_bft, int B, int T, void* d_slots, void* stream) {
   if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_pack_complex: bad argument");
   RFX_ON_DEVICE(plan->device);
-  RFX_HIP(launch_pack_angles((const cf*)d_bft, (cf*)d_slots, B, T, (hipStream_t)stream));
+  if (plan->generic) RFX_HIP(launch_gen_pack(d_bft, d_slots, true, B, plan->n_stft, T, plan->gg.fs, (hipStream_t)stream));
+  else RFX_HIP(launch_pack_angles((const cf*)d_bft, (cf*)d_slots, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
 int rfx_unpack_complex(const rfx_plan* plan, const void* d_slots, int B, int T, void* d_bft, void* stream) {
   if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_unpack_complex: bad argument");
   RFX_ON_DEVICE(plan->device);
-  RFX_HIP(launch_unpack_complex((const cf*)d_slots, (cf*)d_bft, B, T, (hipStream_t)stream));
+  if (plan->generic) RFX_HIP(launch_gen_unpack(d_slots, d_bft, true, B, plan->n_stft, T, plan->gg.fs, (hipStream_t)stream));
+  else RFX_HIP(launch_unpack_complex((const cf*)d_slots, (cf*)d_bft, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
 
@@ -408,8 +474,24 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
              void* stream) {
   if (!plan || !d_wave || B <= 0) return fail(RFX_ERR_INVALID, "rfx_stft: bad argument");
   // torch.stft(center=True, pad_mode="reflect") raises when the pad n_fft/2 is not smaller than the input
-  if (Lw <= kNfft / 2) return fail(RFX_ERR_INVALID, "rfx_stft: reflect padding needs more than n_fft/2 = 8820 samples");
+  if (Lw <= plan->p.n_fft / 2)
+    return fail(RFX_ERR_INVALID, "rfx_stft: reflect padding needs more than n_fft/2 = " + std::to_string(plan->p.n_fft / 2) + " samples");
   RFX_ON_DEVICE(plan->device);
+  if (plan->generic) {
+    GenStftArgs g{};
+    g.g = plan->gg;
+    g.tb = plan->gt;
+    g.wave = d_wave;
+    g.wave_stride = (size_t)Lw;
+    g.mag = d_mag_slots;
+    g.spec = (cf*)d_spec_slots;
+    g.B = B;
+    g.T = 1 + Lw / plan->gg.hop;
+    g.Lw = Lw;
+    if (d_mag_slots) RFX_HIP(launch_gen_stft(0, g, plan->num_cus, (hipStream_t)stream));
+    if (d_spec_slots) RFX_HIP(launch_gen_stft(1, g, plan->num_cus, (hipStream_t)stream));
+    return RFX_OK;
+  }
   StftArgs a;
   a.wave = d_wave;
   a.mag = d_mag_slots;
@@ -442,8 +524,93 @@ static void gl_layout(int B, int T, size_t& off_audio, size_t& off_scale, size_t
   total = o;
 }
 
+// generic path: Z and tprev spectra, the windowed frames, one audio estimate
+static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_z, size_t& off_tprev, size_t& off_frames, size_t& off_audio,
+                          size_t& total, int& Lpad) {
+  const GenGeom& g = plan->gg;
+  const size_t nf = (size_t)B * T;
+  Lpad = (int)align_up((size_t)g.hop * (T - 1), 64);
+  size_t o = 0;
+  off_z = o;
+  o += align_up(nf * g.fs * sizeof(cf), 256);
+  off_tprev = o;
+  o += align_up(nf * g.fs * sizeof(cf), 256);
+  off_frames = o;
+  o += align_up(nf * g.win * sizeof(float), 256);
+  off_audio = o;
+  o += align_up((size_t)B * Lpad * sizeof(float), 256);
+  total = o;
+}
+
+static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* d_angles0, uint64_t seed, int B, int T, int n_iter,
+                          float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream,
+                          float* h_launch_ms) {
+  const GenGeom& g = plan->gg;
+  const int L = g.hop * (T - 1);
+  if (n_iter > 0 && L <= g.n_fft / 2)
+    return fail(RFX_ERR_INVALID, "rfx_griffinlim: Padding size should be less than the corresponding input dimension (reflect padding " +
+                                 std::to_string(g.n_fft / 2) + " needs more than that many samples)");
+  size_t oz, ot, ofr, oa, total;
+  int Lpad;
+  gen_gl_layout(plan, B, T, oz, ot, ofr, oa, total, Lpad);
+  if (workspace_bytes < total) return fail(RFX_ERR_WORKSPACE, "rfx_griffinlim: workspace too small");
+  char* ws = (char*)d_workspace;
+  cf* Z = (cf*)(ws + oz);
+  cf* tprev = (cf*)(ws + ot);
+  float* frames = (float*)(ws + ofr);
+  float* audio = (float*)(ws + oa);
+  EventList events;
+  if (h_launch_ms) {
+    RFX_HIP(events.create(n_iter + 2));
+    RFX_HIP(hipEventRecord(events.ev[0], stream));
+  }
+  GenIstftArgs ia{};
+  ia.g = g;
+  ia.tb = plan->gt;
+  ia.z = Z;
+  ia.S = d_mag;
+  ia.angles0 = (const cf*)d_angles0;
+  ia.seed = seed;
+  ia.frames = frames;
+  ia.B = B;
+  ia.T = T;
+  GenStftArgs sa{};
+  sa.g = g;
+  sa.tb = plan->gt;
+  sa.wave = audio;
+  sa.wave_stride = (size_t)Lpad;
+  sa.S = d_mag;
+  sa.tprev = tprev;
+  sa.z = Z;
+  sa.mom = momentum / (1.f + momentum);
+  sa.B = B;
+  sa.T = T;
+  sa.Lw = L;
+  for (int it = 0; it <= n_iter; ++it) {
+    if (it > 0) {  // rebuilt = STFT(x_{it-1}); Z = S * normalise(rebuilt - m * tprev); tprev = rebuilt
+      sa.first = it == 1;
+      RFX_HIP(launch_gen_stft(2, sa, plan->num_cus, stream));
+    }
+    RFX_HIP(launch_gen_istft(it == 0, ia, plan->num_cus, stream));
+    const bool last = it == n_iter;
+    RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : audio, g, B, T, last ? (size_t)L : (size_t)Lpad, stream));
+    if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
+  }
+  if (h_launch_ms) {
+    RFX_HIP(hipEventSynchronize(events.ev[n_iter + 1]));
+    for (int i = 0; i <= n_iter; ++i) RFX_HIP(hipEventElapsedTime(&h_launch_ms[i], events.ev[i], events.ev[i + 1]));
+  }
+  return RFX_OK;
+}
+
 size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
   if (!plan || B <= 0 || T < 2) return 0;
+  if (plan->generic) {
+    size_t a, b, c, d, total;
+    int Lpad;
+    gen_gl_layout(plan, B, T, a, b, c, d, total, Lpad);
+    return total;
+  }
   size_t a, c, total;
   int Lpad;
   gl_layout(B, T, a, c, total, Lpad);
@@ -456,6 +623,11 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   if (!plan || !d_mag_slots || !d_wave_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_griffinlim: null argument");
   if (B <= 0 || T < 2 || n_iter < 0) return fail(RFX_ERR_INVALID, "rfx_griffinlim: bad shape");
   if (!(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_griffinlim: momentum must be in [0, 1)");
+  if (plan->generic) {
+    RFX_ON_DEVICE(plan->device);
+    return gen_griffinlim(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace, workspace_bytes,
+                          (hipStream_t)stream_, h_launch_ms);
+  }
   // every iteration re-analyses the hop*(T-1)-sample estimate with torch.stft(center=True, reflect):
   // the reference raises there unless the signal is longer than the n_fft/2 padding
   if (n_iter > 0 && kHop * (T - 1) <= kNfft / 2)
@@ -552,28 +724,45 @@ int rfx_griffinlim_timed(const rfx_plan* plan, const float* d_mag_slots, const v
 int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int T, float* d_bft, void* stream) {
   if (!plan || !d_bft || !d_slots || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_unpack_magnitudes: bad argument");
   RFX_ON_DEVICE(plan->device);
-  RFX_HIP(launch_unpack_mag(d_slots, d_bft, B, T, (hipStream_t)stream));
+  if (plan->generic) RFX_HIP(launch_gen_unpack(d_slots, d_bft, false, B, plan->n_stft, T, plan->gg.fs, (hipStream_t)stream));
+  else RFX_HIP(launch_unpack_mag(d_slots, d_bft, B, T, (hipStream_t)stream));
   return RFX_OK;
 }
 
 size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw) {
-  if (!plan || B <= 0 || Lw <= kNfft / 2) return 0;
-  if (plan->fwd_ok && !plan->fwd_unfused) return 256;  // the fused kernel keeps the magnitudes on chip
-  const size_t T = 1 + Lw / kHop;
+  if (!plan || B <= 0 || Lw <= plan->p.n_fft / 2) return 0;
+  const size_t T = 1 + Lw / plan->p.hop_length;
+  if (plan->generic)  // magnitudes [B*T][fs] + frame-major mel amplitudes [B*T][Mpad]
+    return align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256) + align_up((size_t)B * T * plan->Mpad * sizeof(float), 256);
+  // the fused kernel keeps the magnitudes on chip: its scratch is the frame-major copy of the mel amplitudes
+  if (plan->fwd_ok && !plan->fwd_unfused) return align_up((size_t)B * T * plan->Mpad * sizeof(float), 256);
   return align_up((size_t)B * T * kFrameStride * sizeof(float), 256);
 }
 
 int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
                           size_t workspace_bytes, void* stream) {
   if (!plan || !d_wave || !d_mel_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: null argument");
-  if (!plan->d_melfb_slots) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: plan was created without a mel filterbank");
-  if (workspace_bytes < rfx_mel_workspace_bytes(plan, B, Lw) || Lw <= kNfft / 2)
-    return fail(Lw <= kNfft / 2 ? RFX_ERR_INVALID : RFX_ERR_WORKSPACE, "rfx_mel_from_waveform: input too short or workspace too small");
+  if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: plan was created without a mel filterbank");
+  if (workspace_bytes < rfx_mel_workspace_bytes(plan, B, Lw) || Lw <= plan->p.n_fft / 2)
+    return fail(Lw <= plan->p.n_fft / 2 ? RFX_ERR_INVALID : RFX_ERR_WORKSPACE, "rfx_mel_from_waveform: input too short or workspace too small");
   RFX_ON_DEVICE(plan->device);
+  if (plan->generic) {
+    if (!plan->fwd_ok) return fail(RFX_ERR_UNSUPPORTED, "rfx_mel_from_waveform: filterbank is not banded: " + plan->imel_why);
+    const int T = 1 + Lw / plan->gg.hop;
+    float* mag = (float*)d_workspace;
+    float* mel_tm = (float*)((char*)d_workspace + align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256));
+    int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
+    if (rc) return rc;
+    RFX_HIP(launch_gen_mel(mag, mel_tm, plan->d_band_wt, plan->d_band_lo, plan->d_band_lo + plan->Mpad, (long long)B * T, plan->gg.fs,
+                           plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+    RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+    return RFX_OK;
+  }
   if (plan->fwd_ok && !plan->fwd_unfused) {
     StftMelArgs f;
     f.wave = d_wave;
     f.mel = d_mel_out;
+    f.mel_tm = (float*)d_workspace;
     f.tw1 = plan->d_tw1;
     f.tw2 = plan->d_tw2;
     f.win = plan->d_win;
@@ -610,12 +799,29 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
   return RFX_OK;
 }
 
+size_t rfx_mel_scale_workspace_bytes(const rfx_plan* plan, int B, int T) {
+  if (!plan || B <= 0 || T <= 0) return 0;
+  if (plan->generic)
+    return align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256) + align_up((size_t)B * T * plan->Mpad * sizeof(float), 256);
+  return align_up((size_t)B * T * kFrameStride * sizeof(float), 256);
+}
+
 int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_mel_out, void* d_workspace,
                   size_t workspace_bytes, void* stream) {
   if (!plan || !d_lin_bft || !d_mel_out || !d_workspace || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_mel_scale: bad argument");
-  if (!plan->d_melfb_slots) return fail(RFX_ERR_INVALID, "rfx_mel_scale: plan was created without a mel filterbank");
-  if (workspace_bytes < align_up((size_t)B * T * kFrameStride * sizeof(float), 256)) return fail(RFX_ERR_WORKSPACE, "rfx_mel_scale: workspace too small");
+  if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_mel_scale: plan was created without a mel filterbank");
+  if (workspace_bytes < rfx_mel_scale_workspace_bytes(plan, B, T)) return fail(RFX_ERR_WORKSPACE, "rfx_mel_scale: workspace too small");
   RFX_ON_DEVICE(plan->device);
+  if (plan->generic) {
+    if (!plan->fwd_ok) return fail(RFX_ERR_UNSUPPORTED, "rfx_mel_scale: filterbank is not banded: " + plan->imel_why);
+    float* mag = (float*)d_workspace;
+    float* mel_tm = (float*)((char*)d_workspace + align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256));
+    RFX_HIP(launch_gen_pack(d_lin_bft, mag, false, B, plan->n_stft, T, plan->gg.fs, (hipStream_t)stream));
+    RFX_HIP(launch_gen_mel(mag, mel_tm, plan->d_band_wt, plan->d_band_lo, plan->d_band_lo + plan->Mpad, (long long)B * T, plan->gg.fs,
+                           plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+    RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+    return RFX_OK;
+  }
   float* mag = (float*)d_workspace;
   RFX_HIP(launch_pack_mag(d_lin_bft, mag, B, T, (hipStream_t)stream));
   MelArgs a;
@@ -664,6 +870,9 @@ int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int 
   a.M = plan->p.n_mels;
   a.T = T;
   a.C = channels_per_clip;
+  a.n_stft = plan->n_stft;
+  a.out_stride = plan->frame_stride;
+  a.plain = plan->generic ? 1 : 0;
   a.max_iter = plan->p.max_mel_iters;
   a.lr = 0.1f;        // sgdargs=None -> {"lr": 0.1, "momentum": 0.9} (torchaudio 0.13 InverseMelScale)
   a.momentum = 0.9f;

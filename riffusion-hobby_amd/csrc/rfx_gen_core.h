@@ -1,0 +1,159 @@
+// rfx_gen_core.h - per-thread arithmetic of the GENERIC framed transform: any STFT geometry whose n_fft factors
+// into the radices below (every common sample rate: 48 kHz -> n_fft 19200, 32 kHz -> 12800, 22.05 kHz -> 8820,
+// 16 kHz -> 6400, ... at the reference's default 400 / 100 / 10 ms; riffusion/spectrogram_params.py:62-81 derives the
+// three lengths from the sample rate with int() truncation).  Written once for the gfx950 kernels (hipcc) and for the
+// host-side emulator of the CPU tests (g++), like rfx_core.h for the specialised 44.1 kHz engine.
+//
+// A frame transform is a real FFT of length n_fft of the win_length windowed samples (centred, zero padded):
+//   * n_fft even: the n_fft reals are packed as nc = n_fft/2 complex numbers z[n] = x[2n] + i x[2n+1], one complex
+//     FFT of length nc, then the classic split  X[k] = (Z[k] + conj Z[nc-k])/2 - i w^k (Z[k] - conj Z[nc-k])/2,
+//     w = exp(-2 pi i / n_fft);  the inverse retraces it;
+//   * n_fft odd: a complex FFT of length nc = n_fft on (x, 0).
+// The complex FFT is a Stockham autosort: one pass per radix R over the nc points, reading buffer A and writing
+// buffer B (both in LDS), pass s combining sub-transforms of length Ns = prod of the earlier radices:
+//     v[q]  = in[j + q nc/R] * W_{Ns R}^{q (j mod Ns)}          j = 0 .. nc/R - 1
+//     y     = DFT_R(v)
+//     out[(j div Ns) Ns R + (j mod Ns) + q Ns] = y[q]
+// Twiddles W_nc^t come from a two-level table (W^t = hi[t >> 7] * lo[t & 127], both small enough to sit in LDS next
+// to the two buffers), the R-th roots of a pass are looked up once per thread and pass.
+#pragma once
+#include "rfx_core.h"
+
+namespace rfx {
+
+constexpr int kGenMaxStages = 16;
+constexpr int kGenTwLo = 128;       // entries of the low twiddle table
+constexpr int kGenMaxNc = 10000;    // two LDS buffers of nc complex numbers + tables must fit 160 KiB
+
+struct GenGeom {
+  int n_fft, win, hop, n_stft;
+  int nc;       // length of the complex FFT: n_fft/2 (even n_fft) or n_fft (odd)
+  int even;     // 1: packed-real split
+  int left;     // (n_fft - win) / 2: position of the first windowed sample inside the padded frame
+  int fs;       // elements between consecutive frames of a [B*T][fs] array (n_stft rounded up to 64)
+  int nhi;      // entries of the high twiddle table: ceil(nc / 128) (+1)
+  int nhi2;     // entries of the high table of the split twiddles exp(-2 pi i k / n_fft), k <= nc
+  int nstages;
+  int radix[kGenMaxStages];
+};
+
+// radices the butterfly below implements; 4 first (fewest passes), then the primes
+RFX_HD bool gen_factor(int n, int* radix, int* nstages) {
+  const int cand[7] = {4, 2, 3, 5, 7, 11, 13};
+  int ns = 0;
+  for (int c = 0; c < 7; ++c)
+    while (n % cand[c] == 0) {
+      if (ns == kGenMaxStages) return false;
+      radix[ns++] = cand[c];
+      n /= cand[c];
+    }
+  *nstages = ns;
+  return n == 1;
+}
+
+RFX_HD cf gen_tw(const cf* lo, const cf* hi, int t) { return cmul(hi[t >> 7], lo[t & (kGenTwLo - 1)]); }
+
+template <int R, bool INV>
+RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, int tstep, const cf* lo, const cf* hi,
+                          const cf (&root)[R]) {
+  const int k = j % Ns;
+  cf v[R];
+  v[0] = in[j];
+#pragma unroll
+  for (int q = 1; q < R; ++q) {
+    const cf w = gen_tw(lo, hi, q * k * tstep);  // q * k * tstep < nc
+    v[q] = INV ? cmulc(in[j + q * m], w) : cmul(in[j + q * m], w);
+  }
+  cf y[R];
+  if (R == 2) {
+    y[0] = cf{v[0].re + v[1].re, v[0].im + v[1].im};
+    y[1] = cf{v[0].re - v[1].re, v[0].im - v[1].im};
+  } else if (R == 4) {
+    const cf a{v[0].re + v[2].re, v[0].im + v[2].im}, b{v[0].re - v[2].re, v[0].im - v[2].im};
+    const cf c{v[1].re + v[3].re, v[1].im + v[3].im}, d{v[1].re - v[3].re, v[1].im - v[3].im};
+    // forward: y1 = b - i d, y3 = b + i d ; inverse swaps them
+    const cf md = INV ? cf{-d.im, d.re} : cf{d.im, -d.re};  // (-i d) forward, (+i d) inverse
+    y[0] = cf{a.re + c.re, a.im + c.im};
+    y[2] = cf{a.re - c.re, a.im - c.im};
+    y[1] = cf{b.re + md.re, b.im + md.im};
+    y[3] = cf{b.re - md.re, b.im - md.im};
+  } else {
+#pragma unroll
+    for (int p = 0; p < R; ++p) {
+      cf acc = v[0];
+#pragma unroll
+      for (int q = 1; q < R; ++q) {
+        const cf w = root[(q * p) % R];
+        const cf t = INV ? cmulc(v[q], w) : cmul(v[q], w);
+        acc.re += t.re;
+        acc.im += t.im;
+      }
+      y[p] = acc;
+    }
+  }
+  const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+  for (int p = 0; p < R; ++p) out[j0 + p * Ns] = y[p];
+}
+
+template <int R, bool INV>
+RFX_HD void gen_stage_r(const cf* in, cf* out, int nc, int Ns, const cf* lo, const cf* hi, int tid, int nthr) {
+  const int m = nc / R, tstep = nc / (Ns * R);
+  cf root[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) root[t] = gen_tw(lo, hi, t * m);  // exp(-2 pi i t / R)
+  for (int j = tid; j < m; j += nthr) gen_butterfly<R, INV>(in, out, j, m, Ns, tstep, lo, hi, root);
+}
+
+// one Stockham pass, the share of thread `tid` of `nthr`
+template <bool INV>
+RFX_HD void gen_stage(const cf* in, cf* out, int nc, int Ns, int R, const cf* lo, const cf* hi, int tid, int nthr) {
+  switch (R) {
+    case 2: gen_stage_r<2, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    case 3: gen_stage_r<3, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    case 4: gen_stage_r<4, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    case 5: gen_stage_r<5, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    case 7: gen_stage_r<7, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    case 11: gen_stage_r<11, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    default: gen_stage_r<13, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+  }
+}
+
+// ---- real <-> packed-complex split.  Z: the nc-point complex spectrum (LDS), lo2/hi2: two-level table of
+// exp(-2 pi i k / n_fft).  Returns bin k (0 <= k <= n_fft/2) of the real FFT.
+RFX_HD cf gen_split_forward(const GenGeom& g, const cf* Z, const cf* lo2, const cf* hi2, int k) {
+  if (!g.even) return Z[k];
+  const cf zk = Z[k == g.nc ? 0 : k], zc = Z[k == 0 ? 0 : g.nc - k];
+  const cf s{zk.re + zc.re, zk.im - zc.im}, d{zk.re - zc.re, zk.im + zc.im};  // Z[k] +- conj Z[nc-k]
+  const cf p = cmul(gen_tw(lo2, hi2, k), d);
+  return cf{0.5f * (s.re + p.im), 0.5f * (s.im - p.re)};  // (s - i p) / 2
+}
+// element k (0 <= k < nc) of the complex spectrum whose inverse FFT yields the packed real signal; X(k) fetches bin k of
+// the one-sided spectrum.  Like torch.istft's irfft (pocketfft c2r) the imaginary parts of bins 0 and n_fft/2 are ignored.
+template <class XF>
+RFX_HD cf gen_split_inverse(const GenGeom& g, XF X, const cf* lo2, const cf* hi2, int k) {
+  if (!g.even) {
+    if (k == 0) return cf{X(0).re, 0.f};
+    if (k <= (g.n_fft - 1) / 2) return X(k);
+    const cf c = X(g.n_fft - k);
+    return cf{c.re, -c.im};
+  }
+  cf xk = X(k), xc = X(g.nc - k);
+  if (k == 0) {
+    xk.im = 0.f;
+    xc.im = 0.f;
+  }
+  const cf s{xk.re + xc.re, xk.im - xc.im}, d{xk.re - xc.re, xk.im + xc.im};  // X[k] +- conj X[nc-k]
+  const cf p = cmulc(d, gen_tw(lo2, hi2, k));  // d * exp(+2 pi i k / n_fft)
+  return cf{0.5f * (s.re - p.im), 0.5f * (s.im + p.re)};  // (s + i p) / 2
+}
+
+// Griffin-Lim per-bin update of the generic path, op by op as the reference executes it (torchaudio functional.griffinlim,
+// SURVEY App. A.5): a = rebuilt - m * tprev ; angles = a / (|a| + 1e-16) ; next = S * angles.  IEEE sqrt / divide.
+RFX_HD cf gen_gl_update(cf rebuilt, cf tprev, float mom, float S) {
+  const cf a{rebuilt.re - tprev.re * mom, rebuilt.im - tprev.im * mom};
+  const float den = sqrtf(a.re * a.re + a.im * a.im) + 1e-16f;
+  return cf{S * (a.re / den), S * (a.im / den)};
+}
+
+}  // namespace rfx

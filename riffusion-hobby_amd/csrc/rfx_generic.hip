@@ -1,0 +1,285 @@
+// rfx_generic.hip - the framed transform and Griffin-Lim for ANY STFT geometry (replaces the same torchaudio
+// modules as rfx_stft.hip / rfx_gl.hip: Spectrogram(power=None) and GriffinLim, riffusion/spectrogram_converter.py:47-73).
+//
+// The 44.1 kHz geometry of the reference's defaults runs on the specialised engine (rfx_core.h: hard-wired 40 x 21 x 21
+// factorisation, one fused launch per Griffin-Lim iteration).  Every other sample rate / window / padding the reference
+// accepts (cli.py:43 takes the rate from the input file; spectrogram_params.py:62-81) runs here: a Stockham FFT over a
+// runtime radix list with both buffers in LDS (rfx_gen_core.h), one workgroup per frame, and Griffin-Lim executed in
+// the reference's own op order with its spectral state in HBM:
+//     x_k     = ISTFT(Z_k)                 gen_istft_kernel (frames) + gen_fold_kernel (overlap-add / envelope)
+//     rebuilt = STFT(x_k)                  gen_stft_kernel<GL>, whose epilogue does the per-bin update
+//     Z_{k+1} = S * normalise(rebuilt - m * tprev),  tprev <- rebuilt
+// 36 B per bin and iteration (|S| 4 + tprev 8 + 8 + Z 8 + 8) plus the windowed frames.  Slower than the specialised
+// path by design (about 3x per tile), bit-reproducible (no atomics), same entry points.
+#include <hip/hip_runtime.h>
+
+#include "rfx_gen_core.h"
+#include "rfx_kernels.h"
+
+namespace rfx {
+
+constexpr int kGenThreads = 512;
+
+struct GenLds {
+  cf* a;
+  cf* b;
+  cf* lo;   // [128]  exp(-2 pi i t / nc)
+  cf* hi;   // [nhi]  exp(-2 pi i 128 t / nc)
+  cf* lo2;  // [128]  exp(-2 pi i t / n_fft)
+  cf* hi2;  // [nhi2] exp(-2 pi i 128 t / n_fft)
+};
+
+__device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const GenTables& tb) {
+  GenLds l;
+  l.a = reinterpret_cast<cf*>(smem);
+  l.b = l.a + g.nc;
+  l.lo = l.b + g.nc;
+  l.hi = l.lo + kGenTwLo;
+  l.lo2 = l.hi + g.nhi;
+  l.hi2 = l.lo2 + kGenTwLo;
+  for (int i = threadIdx.x; i < kGenTwLo; i += blockDim.x) {
+    l.lo[i] = tb.lo[i];
+    l.lo2[i] = tb.lo2[i];
+  }
+  for (int i = threadIdx.x; i < g.nhi; i += blockDim.x) l.hi[i] = tb.hi[i];
+  for (int i = threadIdx.x; i < g.nhi2; i += blockDim.x) l.hi2[i] = tb.hi2[i];
+  return l;
+}
+
+size_t gen_lds_bytes(const GenGeom& g) { return sizeof(cf) * (2 * (size_t)g.nc + 2 * kGenTwLo + g.nhi + g.nhi2); }
+
+// all passes of the nc-point FFT; data starts in l.a, the result's buffer is returned.  Barriers inside.
+template <bool INV>
+__device__ __forceinline__ cf* gen_fft(const GenGeom& g, const GenLds& l) {
+  cf* in = l.a;
+  cf* out = l.b;
+  int Ns = 1;
+  for (int s = 0; s < g.nstages; ++s) {
+    __syncthreads();
+    gen_stage<INV>(in, out, g.nc, Ns, g.radix[s], l.lo, l.hi, (int)threadIdx.x, (int)blockDim.x);
+    Ns *= g.radix[s];
+    cf* t = in;
+    in = out;
+    out = t;
+  }
+  __syncthreads();
+  return in;
+}
+
+// ---- forward: frame fr of clip b is centred on sample hop*fr of the reflect-padded waveform (torch.stft center=True)
+enum GenStftMode { kGenMag = 0, kGenSpec = 1, kGenGl = 2 };
+
+template <int MODE>
+__global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GenGeom& g = a.g;
+  const GenLds l = gen_lds(smem, g, a.tb);
+  const long long nframes = (long long)a.B * a.T;
+  const int half = g.n_fft / 2;
+  for (long long fr = blockIdx.x; fr < nframes; fr += gridDim.x) {
+    const int clip = (int)(fr / a.T), t = (int)(fr - (long long)clip * a.T);
+    const float* __restrict__ x = a.wave + (size_t)clip * a.wave_stride;
+    __syncthreads();  // previous frame's epilogue is done with the buffers
+    // windowed, zero-padded frame, packed two reals per complex when n_fft is even
+    for (int n = threadIdx.x; n < g.nc; n += blockDim.x) {
+      float v[2] = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!g.even && e == 1) break;
+        const int i = g.even ? 2 * n + e : n;  // position inside the padded frame
+        const int j = i - g.left;              // position inside the window
+        if (j >= 0 && j < g.win) v[e] = x[reflect_index(g.hop * t + i - half, a.Lw)] * a.tb.win[j];
+      }
+      l.a[n] = cf{v[0], v[1]};
+    }
+    const cf* Z = gen_fft<false>(g, l);
+    const size_t base = (size_t)fr * g.fs;
+    for (int k = threadIdx.x; k < g.fs; k += blockDim.x) {
+      if (k >= g.n_stft) {  // padding of the frame stride: keep it zero
+        if (MODE == kGenMag) a.mag[base + k] = 0.f;
+        if (MODE == kGenSpec) a.spec[base + k] = cf{0.f, 0.f};
+        if (MODE == kGenGl) { a.tprev[base + k] = cf{0.f, 0.f}; a.z[base + k] = cf{0.f, 0.f}; }
+        continue;
+      }
+      const cf X = gen_split_forward(g, Z, l.lo2, l.hi2, k);
+      if (MODE == kGenMag) a.mag[base + k] = sqrtf(fmaf(X.re, X.re, X.im * X.im));
+      if (MODE == kGenSpec) a.spec[base + k] = X;
+      if (MODE == kGenGl) {
+        const cf tp = a.first ? cf{0.f, 0.f} : a.tprev[base + k];
+        a.z[base + k] = gen_gl_update(X, tp, a.mom, a.S[base + k]);
+        a.tprev[base + k] = X;
+      }
+    }
+  }
+}
+
+// ---- inverse: one-sided spectrum of frame fr -> its win_length windowed samples (irfft scaling folded in)
+template <bool INIT>
+__global__ void __launch_bounds__(kGenThreads) gen_istft_kernel(GenIstftArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GenGeom& g = a.g;
+  const GenLds l = gen_lds(smem, g, a.tb);
+  const long long nframes = (long long)a.B * a.T;
+  const float scale = 1.0f / (float)g.nc;  // even: z = IFFT_nc(Z) ; odd: x = Re IFFT_n(Z)
+  for (long long fr = blockIdx.x; fr < nframes; fr += gridDim.x) {
+    const size_t base = (size_t)fr * g.fs;
+    auto X = [&](int k) {
+      if (!INIT) return a.z[base + k];
+      const float s = a.S[base + k];
+      cf ang;
+      if (a.angles0) ang = a.angles0[base + k];
+      else ang = rand_unit_pair(a.seed, (unsigned long long)fr * g.n_stft + k);
+      return cf{s * ang.re, s * ang.im};
+    };
+    __syncthreads();
+    for (int k = threadIdx.x; k < g.nc; k += blockDim.x) l.a[k] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
+    const cf* z = gen_fft<true>(g, l);
+    float* __restrict__ out = a.frames + (size_t)fr * g.win;
+    for (int j = threadIdx.x; j < g.win; j += blockDim.x) {
+      const int i = j + g.left;
+      const float v = g.even ? ((i & 1) ? z[i >> 1].im : z[i >> 1].re) : z[i].re;
+      out[j] = v * scale * a.tb.win[j];
+    }
+  }
+}
+
+// overlap-add of the windowed frames and division by the window envelope (torch.istft center=True, length = hop*(T-1)):
+// sample p of the output sits at P = p + n_fft/2 of the padded signal; frame t contributes its window sample
+// j = P - hop*t - left.  One thread per output sample, fixed summation order (t ascending): bit-reproducible.
+__global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__ frames, const float* __restrict__ win,
+                                                       float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= L) return;
+  const int q = p + g.n_fft / 2 - g.left;  // j = q - hop*t
+  int tlo = q - (g.win - 1) <= 0 ? 0 : (q - (g.win - 1) + g.hop - 1) / g.hop;
+  int thi = q / g.hop;
+  if (thi > T - 1) thi = T - 1;
+  float acc = 0.f, env = 0.f;
+  for (int t = tlo; t <= thi; ++t) {
+    const int j = q - g.hop * t;
+    const float w = win[j];
+    acc += frames[((size_t)b * T + t) * g.win + j];
+    env = fmaf(w, w, env);
+  }
+  out[(size_t)b * out_stride + p] = acc / env;
+}
+
+// ---- (B, F, T) <-> [B*T][fs] layout conversion (tiled transposes; the padding of the frame stride is zeroed)
+template <class V>
+__global__ void __launch_bounds__(256) gen_pack_kernel(const V* __restrict__ bft, V* __restrict__ frames, int F, int T, int fs) {
+  __shared__ V tile[32][33];
+  const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32, b = blockIdx.z;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  for (int r = ly; r < 32; r += 8) {
+    const int f = f0 + r, t = t0 + lx;
+    tile[r][lx] = (f < F && t < T) ? bft[((size_t)b * F + f) * T + t] : V{};
+  }
+  __syncthreads();
+  for (int r = ly; r < 32; r += 8) {
+    const int t = t0 + r, f = f0 + lx;
+    if (t < T && f < fs) frames[((size_t)b * T + t) * fs + f] = tile[lx][r];
+  }
+}
+template <class V>
+__global__ void __launch_bounds__(256) gen_unpack_kernel(const V* __restrict__ frames, V* __restrict__ bft, int F, int T, int fs) {
+  __shared__ V tile[32][33];
+  const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32, b = blockIdx.z;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  for (int r = ly; r < 32; r += 8) {
+    const int t = t0 + r, f = f0 + lx;
+    tile[r][lx] = (t < T && f < F) ? frames[((size_t)b * T + t) * fs + f] : V{};
+  }
+  __syncthreads();
+  for (int r = ly; r < 32; r += 8) {
+    const int f = f0 + r, t = t0 + lx;
+    if (f < F && t < T) bft[((size_t)b * F + f) * T + t] = tile[lx][r];
+  }
+}
+
+// ---- banded mel projection of magnitude frames [B*T][fs] -> frame-major (B, T, Mpad), one workgroup per frame
+__global__ void __launch_bounds__(256) gen_mel_kernel(const float* __restrict__ mag, float* __restrict__ mel_tm,
+                                                      const float* __restrict__ band_wt, const int* __restrict__ band_lo,
+                                                      const int* __restrict__ band_len, int fs, int M, int Mpad) {
+  const size_t fr = blockIdx.x;
+  const float* __restrict__ row = mag + fr * fs;
+  for (int m = threadIdx.x; m < Mpad; m += blockDim.x) {
+    float s = 0.f;
+    if (m < M) {
+      const int lo = band_lo[m], n = band_len[m];
+      for (int i = 0; i < n; ++i) s = fmaf(band_wt[(size_t)i * Mpad + m], row[lo + i], s);
+    }
+    mel_tm[fr * Mpad + m] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+static int gen_grid(const GenGeom& g, int num_cus, long long nframes) {
+  // resident workgroups: LDS bound (160 KiB per CU)
+  const size_t lds = gen_lds_bytes(g);
+  int per_cu = (int)((160u * 1024u) / (lds + 512));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;  // 512 threads each: 16 waves per workgroup, 32 waves per CU at most sensible
+  long long n = (long long)num_cus * per_cu;
+  return (int)(n < nframes ? n : nframes);
+}
+
+hipError_t prepare_generic_kernels(const GenGeom& g) {
+  const int lds = (int)gen_lds_bytes(g);
+  hipError_t e;
+#define RFX_SET(k) if ((e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e
+  RFX_SET(gen_stft_kernel<kGenMag>);
+  RFX_SET(gen_stft_kernel<kGenSpec>);
+  RFX_SET(gen_stft_kernel<kGenGl>);
+  RFX_SET(gen_istft_kernel<true>);
+  RFX_SET(gen_istft_kernel<false>);
+#undef RFX_SET
+  return hipSuccess;
+}
+
+hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream) {
+  const int grid = gen_grid(a.g, num_cus, (long long)a.B * a.T);
+  const size_t lds = gen_lds_bytes(a.g);
+  switch (mode) {
+    case kGenMag: hipLaunchKernelGGL(gen_stft_kernel<kGenMag>, dim3(grid), dim3(kGenThreads), lds, stream, a); break;
+    case kGenSpec: hipLaunchKernelGGL(gen_stft_kernel<kGenSpec>, dim3(grid), dim3(kGenThreads), lds, stream, a); break;
+    default: hipLaunchKernelGGL(gen_stft_kernel<kGenGl>, dim3(grid), dim3(kGenThreads), lds, stream, a); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_istft(bool init, const GenIstftArgs& a, int num_cus, hipStream_t stream) {
+  const int grid = gen_grid(a.g, num_cus, (long long)a.B * a.T);
+  const size_t lds = gen_lds_bytes(a.g);
+  if (init) hipLaunchKernelGGL(gen_istft_kernel<true>, dim3(grid), dim3(kGenThreads), lds, stream, a);
+  else hipLaunchKernelGGL(gen_istft_kernel<false>, dim3(grid), dim3(kGenThreads), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, size_t out_stride,
+                           hipStream_t stream) {
+  const int L = g.hop * (T - 1);
+  hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, win, out, g, B, T, L, out_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream) {
+  dim3 grid((fs + 31) / 32, (T + 31) / 32, B);
+  if (complex_) hipLaunchKernelGGL(gen_pack_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)bft, (float2*)frames, F, T, fs);
+  else hipLaunchKernelGGL(gen_pack_kernel<float>, grid, dim3(256), 0, stream, (const float*)bft, (float*)frames, F, T, fs);
+  return hipGetLastError();
+}
+hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B, int F, int T, int fs, hipStream_t stream) {
+  dim3 grid((F + 31) / 32, (T + 31) / 32, B);
+  if (complex_) hipLaunchKernelGGL(gen_unpack_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)frames, (float2*)bft, F, T, fs);
+  else hipLaunchKernelGGL(gen_unpack_kernel<float>, grid, dim3(256), 0, stream, (const float*)frames, (float*)bft, F, T, fs);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_mel(const float* mag, float* mel_tm, const float* band_wt, const int* band_lo, const int* band_len, long long nframes,
+                          int fs, int M, int Mpad, hipStream_t stream) {
+  hipLaunchKernelGGL(gen_mel_kernel, dim3((unsigned)nframes), dim3(256), 0, stream, mag, mel_tm, band_wt, band_lo, band_len, fs, M, Mpad);
+  return hipGetLastError();
+}
+
+}  // namespace rfx

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
   const int tid = threadIdx.x;
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
-  const int n_stft = kBins;
+  const int n_stft = a.n_stft;
 
   for (int i = tid; i < tb.nnz; i += kImelThreads) w_s[i] = tb.csr_w[i];
   if (tid == 0) diff_s[a.M] = 0.f;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
   }
 
   // ---- results: moved bins from registers, untouched bins straight from the init
-  float* out = a.out_slots + (size_t)frame * kFrameStride;
+  float* out = a.out_slots + (size_t)frame * a.out_stride;
 #pragma unroll
   for (int j = 0; j < BPT; ++j) {
     const int f = tb.f_lo + tid + kImelThreads * j;
@@ -162,10 +162,14 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
     const int p2 = tb.bin_pos2[f];
     if (p2 >= 0) out[p2] = v;
   }
-  // padding lanes of the slot layout are zeroed so that later consumers never see garbage
-  for (int p = tid; p < kFrameStride; p += kImelThreads) {
-    int q, kb;
-    if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
+  // padding positions are zeroed so that later consumers never see garbage
+  if (a.plain) {
+    for (int p = n_stft + tid; p < a.out_stride; p += kImelThreads) out[p] = 0.f;
+  } else {
+    for (int p = tid; p < kFrameStride; p += kImelThreads) {
+      int q, kb;
+      if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
+    }
   }
   if (a.loss_hist && !a.it_limit)
     for (int i = tid; i < a.max_iter; i += kImelThreads) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? hist_s[i] : 0.f;

@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "rfx_core.h"
+#include "rfx_gen_core.h"
 
 namespace rfx {
 
@@ -52,7 +53,8 @@ hipError_t launch_stft(const StftArgs& a, hipStream_t stream);
 // amplitudes leaves the chip.  Valid for banded filterbanks (every filter's support one contiguous run of bins).
 struct StftMelArgs {
   const float* wave;     // [B][Lw]
-  float* mel;            // [B][M][T]
+  float* mel;            // [B][M][T] result (written by the transpose that follows the transform kernel)
+  float* mel_tm;         // [B][T][Mpad] frame-major scratch the transform kernel writes
   const cf* tw1;
   const cf* tw2;
   const float* win;
@@ -106,6 +108,9 @@ struct ImelArgs {
   float* loss_hist;      // [B*T][max_iter] per-frame sum_m diff^2 before each step
   const int* it_limit;   // optional [nclips] number of steps to run (fix-up pass), NULL = max_iter
   int B, M, T, C;        // C = channels per clip (the loss mean couples them)
+  int n_stft;            // linear bins per frame (8821 on the specialised geometry)
+  int out_stride;        // elements between output frames (kFrameStride, or the generic path's fs)
+  int plain;             // 1: output frames are plain bin-ordered rows (generic path), 0: slot layout
   int max_iter;
   float lr, momentum;
   unsigned long long seed;
@@ -114,6 +119,50 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream);  // 
 // scans loss_hist for the early-stop condition; it_stop[clip] = steps the reference would have run
 hipError_t launch_imel_scan(const float* loss_hist, int* it_stop, int* any_early, int nclips, int C, int T, int max_iter,
                             float tol_loss, float tol_change, hipStream_t stream);
+
+// ---- generic-geometry path (rfx_generic.hip): any n_fft / win_length / hop_length, plain [B*T][fs] frame arrays
+struct GenTables {
+  const cf* lo;      // [128]   exp(-2 pi i t / nc)
+  const cf* hi;      // [nhi]   exp(-2 pi i 128 t / nc)
+  const cf* lo2;     // [128]   exp(-2 pi i t / n_fft)
+  const cf* hi2;     // [nhi2]  exp(-2 pi i 128 t / n_fft)
+  const float* win;  // [win]
+};
+struct GenStftArgs {
+  GenGeom g;
+  GenTables tb;
+  const float* wave;   // [B][wave_stride], Lw valid samples each
+  size_t wave_stride;
+  float* mag;          // mode 0: [B*T][fs] |X|
+  cf* spec;            // mode 1: [B*T][fs] X
+  const float* S;      // mode 2 (Griffin-Lim update): magnitudes
+  cf* tprev;           //         previous rebuilt spectrum, read (unless first) and replaced
+  cf* z;               //         next spectrum estimate S * angles
+  float mom;
+  int first;
+  int B, T, Lw;
+};
+struct GenIstftArgs {
+  GenGeom g;
+  GenTables tb;
+  const cf* z;         // spectrum estimate [B*T][fs] (iterations)
+  const float* S;      // init: magnitudes ...
+  const cf* angles0;   //       ... times injected angles, or drawn from `seed` when null
+  unsigned long long seed;
+  float* frames;       // [B*T][win] windowed, scaled frames
+  int B, T;
+};
+hipError_t prepare_generic_kernels(const GenGeom& g);
+size_t gen_lds_bytes(const GenGeom& g);
+hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream);  // mode 0 mag, 1 spec, 2 Griffin-Lim
+hipError_t launch_gen_istft(bool init, const GenIstftArgs& a, int num_cus, hipStream_t stream);
+hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, size_t out_stride,
+                           hipStream_t stream);
+hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
+hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
+hipError_t launch_gen_mel(const float* mag, float* mel_tm, const float* band_wt, const int* band_lo, const int* band_len, long long nframes,
+                          int fs, int M, int Mpad, hipStream_t stream);
+hipError_t launch_mel_transpose(const float* mel_tm, float* mel, int B, int T, int M, int Mpad, hipStream_t stream);
 
 // image / PCM codecs
 hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out, int N, int H, int W, int C, hipStream_t s);

@@ -203,13 +203,21 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
     {
       // eight weights / magnitudes in flight per step (the table is zero-padded to a multiple of eight rows and the
       // magnitude index is clamped, so the tail multiplies finite values by zero); bins are summed in increasing order
+      // the weights of step i+1 are requested before step i is summed (L2 latency hidden behind the LDS reads + FMAs)
       auto band_dot = [&](int m, int lo, int n) {
         const float* __restrict__ wt = a.band_wt + m;
         float s = 0.f;
+        float wn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wn[j] = wt[(size_t)j * a.Mpad];
         for (int i = 0; i < n; i += 8) {
           float w[8], v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = wt[(size_t)(i + j) * a.Mpad];
+          for (int j = 0; j < 8; ++j) w[j] = wn[j];
+          if (i + 8 < n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wn[j] = wt[(size_t)(i + 8 + j) * a.Mpad];
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = magb[min(lo + i + j, nb - 1)];
 #pragma unroll
@@ -217,17 +225,44 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
         }
         return s;
       };
-      if (has0) a.mel[((size_t)clip * a.M + m0) * a.T + fr] = band_dot(m0, lo0, n0);
-      if (has1) a.mel[((size_t)clip * a.M + m1) * a.T + fr] = band_dot(m1, lo1, n1);  // first waves only (M <= 896)
+      // frame-major scratch (512 contiguous floats per frame: whole-line stores); a tiled transpose brings it into the
+      // reference's (B, M, T) layout afterwards - 4-byte stores T floats apart cost 10x the bytes in HBM writes
+      float* __restrict__ row = a.mel_tm + ((size_t)clip * a.T + fr) * a.Mpad;
+      if (m0 < a.Mpad) row[m0] = has0 ? band_dot(m0, lo0, n0) : 0.f;
+      if (m1 < a.Mpad) row[m1] = has1 ? band_dot(m1, lo1, n1) : 0.f;  // first waves only (M <= 896)
     }
     __syncthreads();  // the next frame's P1 overwrites the magnitudes
   }
 }
 
+// (B, T, Mpad) frame-major mel amplitudes -> the reference's (B, M, T): 64 x 64 tiles through LDS, both sides coalesced
+__global__ void __launch_bounds__(256) mel_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int M, int Mpad) {
+  __shared__ float tile[64][65];
+  const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, b = blockIdx.z;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = ly; r < 64; r += 4) {
+    const int tt = t0 + r;
+    tile[r][lx] = tt < T ? in[((size_t)b * T + tt) * Mpad + m0 + lx] : 0.f;  // m0 + lx < Mpad always (Mpad % 64 == 0)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ly; r < 64; r += 4) {
+    const int m = m0 + r, tt = t0 + lx;
+    if (m < M && tt < T) out[((size_t)b * M + m) * T + tt] = tile[lx][r];
+  }
+}
+
+hipError_t launch_mel_transpose(const float* mel_tm, float* mel, int B, int T, int M, int Mpad, hipStream_t stream) {
+  hipLaunchKernelGGL(mel_transpose_kernel, dim3((T + 63) / 64, Mpad / 64, B), dim3(256), 0, stream, mel_tm, mel, T, M, Mpad);
+  return hipGetLastError();
+}
+
 hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream) {
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   hipLaunchKernelGGL(stft_mel_kernel, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
-  return hipGetLastError();
+  const hipError_t e = hipGetLastError();
+  return e != hipSuccess ? e : launch_mel_transpose(a.mel_tm, a.mel, a.B, a.T, a.M, a.Mpad, stream);
 }
 
 hipError_t prepare_frame_kernels() {

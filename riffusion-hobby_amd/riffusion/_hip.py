@@ -54,6 +54,9 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_version": (c_int, []),
     "rfx_frame_stride": (c_int, []),
     "rfx_num_bins": (c_int, []),
+    "rfx_plan_frame_stride": (c_int, [c_void_p]),
+    "rfx_plan_is_generic": (c_int, [c_void_p]),
+    "rfx_mel_scale_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_plan_create": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "rfx_plan_destroy": (c_int, [c_void_p]),
     "rfx_pack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -209,7 +212,8 @@ class Plan:
             )
         )
         self.handle = handle
-        self.frame_stride = self.lib.rfx_frame_stride()
+        self.frame_stride = self.lib.rfx_plan_frame_stride(self.handle)
+        self.generic = bool(self.lib.rfx_plan_is_generic(self.handle))
 
     def __del__(self):
         try:
@@ -368,7 +372,7 @@ class Plan:
         B, F, Tn = lin_bft.shape
         if F != self.n_stft:
             raise ValueError(f"expected {self.n_stft} linear bins, got {F}")
-        ws = torch.empty(B * Tn * self.frame_stride * 4 + 256, dtype=torch.uint8, device=lin_bft.device)
+        ws = torch.empty(self.lib.rfx_mel_scale_workspace_bytes(self.handle, B, Tn), dtype=torch.uint8, device=lin_bft.device)
         out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=lin_bft.device)
         check(self.lib.rfx_mel_scale(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out

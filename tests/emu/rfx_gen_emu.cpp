@@ -1,0 +1,89 @@
+// Host-side emulator of the GENERIC frame transform (csrc/rfx_gen_core.h).  TEST INFRASTRUCTURE ONLY, built with g++ by
+// tests/test_gen_core.py: it runs the same Stockham pass / real-split functions the gfx950 kernels inline, looping over the
+// logical threads of a workgroup pass by pass (a loop boundary stands where the kernel has a barrier).
+#include <cmath>
+#include <vector>
+#include "../../riffusion-hobby_amd/csrc/rfx_gen_core.h"
+
+using namespace rfx;
+
+namespace {
+struct Tables {
+  std::vector<cf> lo, hi, lo2, hi2;
+};
+bool make_geom(int n_fft, int win, int hop, GenGeom& g, Tables& t) {
+  g = GenGeom{};
+  g.n_fft = n_fft; g.win = win; g.hop = hop; g.n_stft = n_fft / 2 + 1;
+  g.even = n_fft % 2 == 0;
+  g.nc = g.even ? n_fft / 2 : n_fft;
+  g.left = (n_fft - win) / 2;
+  g.fs = (g.n_stft + 63) / 64 * 64;
+  g.nhi = g.nc / kGenTwLo + 1;
+  g.nhi2 = g.nc / kGenTwLo + 2;
+  if (!gen_factor(g.nc, g.radix, &g.nstages)) return false;
+  const double PI2 = 6.283185307179586476925286766559;
+  auto root = [&](long long num, long long den) {
+    const double a = -PI2 * (double)(num % den) / (double)den;
+    return cf{(float)cos(a), (float)sin(a)};
+  };
+  t.lo.resize(kGenTwLo); t.lo2.resize(kGenTwLo); t.hi.resize(g.nhi); t.hi2.resize(g.nhi2);
+  for (int i = 0; i < kGenTwLo; ++i) { t.lo[i] = root(i, g.nc); t.lo2[i] = root(i, g.n_fft); }
+  for (int i = 0; i < g.nhi; ++i) t.hi[i] = root((long long)i * kGenTwLo, g.nc);
+  for (int i = 0; i < g.nhi2; ++i) t.hi2[i] = root((long long)i * kGenTwLo, g.n_fft);
+  return true;
+}
+template <bool INV>
+cf* run_fft(const GenGeom& g, const Tables& t, cf* a, cf* b, int nthr) {
+  cf *in = a, *out = b;
+  int Ns = 1;
+  for (int s = 0; s < g.nstages; ++s) {
+    for (int tid = 0; tid < nthr; ++tid) gen_stage<INV>(in, out, g.nc, Ns, g.radix[s], t.lo.data(), t.hi.data(), tid, nthr);
+    Ns *= g.radix[s];
+    cf* x = in; in = out; out = x;
+  }
+  return in;
+}
+}  // namespace
+
+extern "C" {
+
+// returns the number of passes (0: unsupported length); radices written to radix_out[16]
+int emu_gen_factor(int n_fft, int* radix_out) {
+  GenGeom g; Tables t;
+  if (!make_geom(n_fft, n_fft, 1, g, t)) return 0;
+  for (int i = 0; i < g.nstages; ++i) radix_out[i] = g.radix[i];
+  return g.nstages;
+}
+
+// frame: n_fft reals (already windowed / zero padded) -> n_stft complex bins (interleaved re, im)
+int emu_gen_rfft(int n_fft, const float* frame, float* out, int nthr) {
+  GenGeom g; Tables t;
+  if (!make_geom(n_fft, n_fft, 1, g, t)) return -1;
+  std::vector<cf> a(g.nc), b(g.nc);
+  for (int n = 0; n < g.nc; ++n) a[n] = g.even ? cf{frame[2 * n], frame[2 * n + 1]} : cf{frame[n], 0.f};
+  const cf* Z = run_fft<false>(g, t, a.data(), b.data(), nthr);
+  for (int k = 0; k < g.n_stft; ++k) {
+    const cf X = gen_split_forward(g, Z, t.lo2.data(), t.hi2.data(), k);
+    out[2 * k] = X.re; out[2 * k + 1] = X.im;
+  }
+  return 0;
+}
+
+// n_stft complex bins -> n_fft reals, scaled like numpy / torch irfft (1/n_fft)
+int emu_gen_irfft(int n_fft, const float* spec, float* out, int nthr) {
+  GenGeom g; Tables t;
+  if (!make_geom(n_fft, n_fft, 1, g, t)) return -1;
+  std::vector<cf> a(g.nc), b(g.nc);
+  auto X = [&](int k) { return cf{spec[2 * k], spec[2 * k + 1]}; };
+  for (int k = 0; k < g.nc; ++k) a[k] = gen_split_inverse(g, X, t.lo2.data(), t.hi2.data(), k);
+  const cf* z = run_fft<true>(g, t, a.data(), b.data(), nthr);
+  const float scale = 1.0f / (float)g.nc;
+  for (int i = 0; i < n_fft; ++i) out[i] = (g.even ? ((i & 1) ? z[i >> 1].im : z[i >> 1].re) : z[i].re) * scale;
+  return 0;
+}
+
+void emu_gen_gl_update(const float* rebuilt, const float* tprev, float mom, float S, float* out) {
+  const cf z = gen_gl_update(cf{rebuilt[0], rebuilt[1]}, cf{tprev[0], tprev[1]}, mom, S);
+  out[0] = z.re; out[1] = z.im;
+}
+}
