@@ -334,7 +334,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     // group formulation (fast kernel): active bins contiguous with no zero row inside, first-filter index
     // non-decreasing, and the per-thread pairing (short group t, long group M-1-t) fits 8 + 24 registers
     std::vector<int> grp_start(M + 1, 0);
-    bool fast = ok && M <= 512 && !generic, perwave = false;  // the group kernels are written for the slot layout
+    bool fast = ok && M <= 512, perwave = false;
     if (fast) {
       int prev = 0;
       for (int f = f_lo; f < f_hi && fast; ++f) {

@@ -10,7 +10,7 @@
 //     rebuilt = STFT(x_k)                  gen_stft_kernel<GL>, whose epilogue does the per-bin update
 //     Z_{k+1} = S * normalise(rebuilt - m * tprev),  tprev <- rebuilt
 // 36 B per bin and iteration (|S| 4 + tprev 8 + 8 + Z 8 + 8) plus the windowed frames.  Slower than the specialised
-// path by design (about 3x per tile), bit-reproducible (no atomics), same entry points.
+// path by design (measured: 4-7x per tile), bit-reproducible (no atomics), same entry points.
 #include <hip/hip_runtime.h>
 
 #include "rfx_gen_core.h"
@@ -18,7 +18,7 @@
 
 namespace rfx {
 
-constexpr int kGenThreads = 512;
+constexpr int kGenThreads = 1024;  // 16 waves: the LDS footprint allows one workgroup per CU at 48 kHz, so it has to fill the CU alone
 
 struct GenLds {
   cf* a;
@@ -219,7 +219,7 @@ static int gen_grid(const GenGeom& g, int num_cus, long long nframes) {
   const size_t lds = gen_lds_bytes(g);
   int per_cu = (int)((160u * 1024u) / (lds + 512));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 4) per_cu = 4;  // 512 threads each: 16 waves per workgroup, 32 waves per CU at most sensible
+  if (per_cu > 2) per_cu = 2;  // 1024 threads each: two workgroups fill the CU's 32 wave slots
   long long n = (long long)num_cus * per_cu;
   return (int)(n < nframes ? n : nframes);
 }

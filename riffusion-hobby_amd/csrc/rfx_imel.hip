@@ -216,7 +216,7 @@ __device__ __forceinline__ void group_load(GroupState<N>& g, int grp, const Imel
     const int f = g.f0 + (ok ? i : 0);
     g.w0[i] = ok ? tb.bin_w0[f] : 0.f;
     g.w1[i] = ok ? tb.bin_w1[f] : 0.f;
-    g.spec[i] = ok ? (a.spec0 ? a.spec0[(size_t)frame * kBins + f] : rand_unit(a.seed, rbase + f)) : 0.f;
+    g.spec[i] = ok ? (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(a.seed, rbase + f)) : 0.f;
     g.buf[i] = 0.f;
   }
 }
@@ -275,7 +275,7 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem) {
   const int tid = threadIdx.x;
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;
-  const unsigned long long rbase = (unsigned long long)frame * kBins;
+  const unsigned long long rbase = (unsigned long long)frame * a.n_stft;
 
   const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;           // long groups, counted down from the top
   const int gL = (tid < M - kImelThreads) ? tid : -1;             // short groups, counted up from 0
@@ -319,19 +319,23 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem) {
   }
   __syncthreads();
 
-  float* out = a.out_slots + (size_t)frame * kFrameStride;
+  float* out = a.out_slots + (size_t)frame * a.out_stride;
   group_store(lo, tb, out);
   group_store(hi, tb, out);
-  for (int f = tid; f < kBins; f += kImelThreads) {
+  for (int f = tid; f < a.n_stft; f += kImelThreads) {
     if (f >= tb.f_lo && f < tb.f_hi) continue;
-    const float v = a.spec0 ? a.spec0[(size_t)frame * kBins + f] : rand_unit(a.seed, rbase + f);
+    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(a.seed, rbase + f);
     out[tb.bin_pos[f]] = v;
     const int p2 = tb.bin_pos2[f];
     if (p2 >= 0) out[p2] = v;
   }
-  for (int p = tid; p < kFrameStride; p += kImelThreads) {
-    int q, kb;
-    if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
+  if (a.plain) {  // generic engine: bin-ordered rows, zero the tail of the frame stride
+    for (int p = a.n_stft + tid; p < a.out_stride; p += kImelThreads) out[p] = 0.f;
+  } else {
+    for (int p = tid; p < kFrameStride; p += kImelThreads) {
+      int q, kb;
+      if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
+    }
   }
   if (a.loss_hist && !a.it_limit)
     for (int i = tid; i < a.max_iter; i += kImelThreads) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? hist_s[i] : 0.f;
