@@ -109,6 +109,7 @@ struct rfx_plan {
   // fused forward path (banded mel projection inside the STFT kernel), valid when fwd_ok
   bool fwd_ok = false;
   float* d_band_wt = nullptr;      // [band_rows][Mpad]
+  int* d_band_addr = nullptr;      // [band_rows][Mpad] LDS position of each band bin (specialised engine)
   int* d_band_lo = nullptr;        // [Mpad] followed by band_len [Mpad]
   int band_rows = 0, Mpad = 0;
   bool fwd_unfused = false;        // debugging override (RFX_FWD_UNFUSED), read once at creation
@@ -367,7 +368,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     pl->imel_ok = ok;
     pl->imel_why = why;
     // ---- fused forward path: per-filter band tables, weights transposed so that lane m reads row i coalesced
-    if (ok && (generic || (M <= 2 * kThreads && (size_t)(f_hi - f_lo) * sizeof(float) <= (size_t)kCubeElems * sizeof(cf)))) {
+    if (ok && (generic || M <= 2 * kThreads)) {
       const int Mpad = (M + 63) / 64 * 64;
       int rows = 1;
       for (int m = 0; m < M; ++m) rows = band_hi[m] - band_lo[m] > rows ? band_hi[m] - band_lo[m] : rows;
@@ -381,6 +382,17 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
       }
       RFX_HIP(hipMalloc(&pl->d_band_wt, wt.size() * sizeof(float)));
       RFX_HIP(hipMemcpy(pl->d_band_wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+      if (!generic) {  // where the fused kernel finds bin f in LDS: float view of the cube, primary slot of the bin
+        std::vector<int> addr((size_t)rows * Mpad, 0);
+        for (int m = 0; m < M; ++m)
+          for (int f = band_lo[m]; f < band_hi[m]; ++f) {
+            const int k = (f % 40 > 20) ? kNfft - f : f;  // bins with residue 21..39 live in conjugate slots
+            const int k1 = k % 40, kp = k / 40;
+            addr[(size_t)(f - band_lo[m]) * Mpad + m] = 2 * cube_at(k1, kp % 21, 0) + kp / 21;
+          }
+        RFX_HIP(hipMalloc(&pl->d_band_addr, addr.size() * sizeof(int)));
+        RFX_HIP(hipMemcpy(pl->d_band_addr, addr.data(), addr.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
       RFX_HIP(hipMalloc(&pl->d_band_lo, lo_len.size() * sizeof(int)));
       RFX_HIP(hipMemcpy(pl->d_band_lo, lo_len.data(), lo_len.size() * sizeof(int), hipMemcpyHostToDevice));
       pl->band_rows = rows;
@@ -442,6 +454,7 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_imel_blob);
     (void)hipFree(plan->d_band_wt);
     (void)hipFree(plan->d_band_lo);
+    (void)hipFree(plan->d_band_addr);
     (void)hipFree(plan->d_gen_tables);
   }
   delete plan;
@@ -767,6 +780,7 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     f.tw2 = plan->d_tw2;
     f.win = plan->d_win;
     f.band_wt = plan->d_band_wt;
+    f.band_addr = plan->d_band_addr;
     f.band_lo = plan->d_band_lo;
     f.band_len = plan->d_band_lo + plan->Mpad;
     f.B = B;

@@ -51,7 +51,16 @@ constexpr int kHalfHops = 5;     // frame t is centred on sample 441*t: it spans
 #endif
 constexpr int kRowStride = RFX_ROW_STRIDE;          // LDS elements between cube rows (>= 441)
 constexpr int kCubeElems = 20 * kRowStride + kHop;
-constexpr int kThreads = 448;    // 7 waves x 64; lane 63 of every wave idles (7 x 63 = 441)
+// Workgroup shape of the frame engine.  The 441 thread roles (P1: n'; P2/P3: (row k1, idx)) are dealt to waves by whole
+// rows, so that the P2 <-> P3 exchange stays inside a wave: 7 waves x 3 rows fill 63 of 64 lanes.  A CU holds two
+// workgroups (LDS) = 14 waves on four SIMDs = 4/4/3/3.  RFX_WAVES=8 (five waves with 3 rows, three with 2) puts 4 waves
+// on EVERY SIMD at the same per-wave instruction stream; measured SLOWER (27.4 vs 26.2 ms per 64 tiles x 32 iterations):
+// the kernel is bound by aggregate instruction issue, not by the imbalance.
+#ifndef RFX_WAVES
+#define RFX_WAVES 7
+#endif
+constexpr int kWaves = RFX_WAVES;
+constexpr int kThreads = 64 * kWaves;
 
 RFX_HD cf cmul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 // a * conj(b)

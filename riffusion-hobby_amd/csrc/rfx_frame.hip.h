@@ -1,6 +1,6 @@
 // rfx_frame.hip.h - device-side frame engine shared by the Griffin-Lim and the forward STFT kernels.
 //
-// One workgroup = 7 waves (448 threads, lane 63 of each wave idle) owns one frame at a time and
+// One workgroup = kWaves waves (rfx_core.h; 7 x 63 or 5 x 63 + 3 x 42 active lanes) owns one frame at a time and
 // keeps the 21 x 441 complex slot matrix ("cube", 74 088 B) in LDS, followed by the 21 x 21 table
 // of w441 twiddles (3 528 B): 77 616 B per workgroup, so two workgroups share a CU's 160 KiB and
 // one's LDS-exchange / HBM phases overlap the other's butterflies.  Thread roles by pass:
@@ -72,18 +72,25 @@ struct ThreadId {
   int idx;   // lane % 21
   int npr;   // P1 index n' (== P3 index q = k1*21+ka)
   int k1;    // row owned in P2/P3
+  int pad;   // 0..6: this (idle) lane zeroes padding position 64*pad+63 of the HBM slot groups; -1 otherwise
   bool active;
 };
 
 __device__ __forceinline__ ThreadId thread_id() {
   ThreadId t;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  t.active = lane < 63;
-  const int l = t.active ? lane : 62;  // idle lane shadows lane 62 (loads only, never stores)
+  static_assert(kWaves == 7 || kWaves == 8, "7 waves x 3 rows, or 5 x 3 + 3 x 2 rows");
+  // kWaves == 8: waves 0..4 own rows 3w..3w+2, waves 5..7 rows 15+2(w-5) and the next one
+  const int rows = (kWaves == 7 || wave < 5) ? 3 : 2;
+  const int row0 = (kWaves == 7 || wave < 5) ? 3 * wave : 15 + 2 * (wave - 5);
+  t.active = lane < 21 * rows;
+  const int l = t.active ? lane : 21 * rows - 1;  // idle lanes shadow the wave's last active lane (loads only, never stores)
   const int row3 = l / 21;
   t.idx = l - 21 * row3;
-  t.k1 = wave * 3 + row3;
-  t.npr = wave * 63 + l;
+  t.k1 = row0 + row3;
+  t.npr = t.k1 * 21 + t.idx;
+  if (kWaves == 7) t.pad = lane == 63 ? wave : -1;
+  else t.pad = (wave == 7 && lane >= 42 && lane < 49) ? lane - 42 : -1;
   return t;
 }
 
@@ -175,6 +182,12 @@ __device__ __forceinline__ void frame_forward_tw(const float (&u)[10], cf (&R)[2
   if (t.active) p1_forward_store(u, [&tw](int k) { return tw.w[k]; }, f.cube, t.npr);
   before_barrier();
   __syncthreads();
+#ifndef RFX_NO_PRIO
+  // the long barrier-free stretch (P2 .. P2', ~1450 instructions per wave) runs at raised priority, the short one
+  // between the synthesis barrier and the next analysis barrier at normal priority: measured 1-2 % (26.9 -> 26.2-26.5 ms
+  // per 64 tiles x 32 iterations); the opposite assignment and __launch_bounds__ min-waves 3 were slower
+  __builtin_amdgcn_s_setprio(2);
+#endif
   after_barrier();
   if (t.active) {
     Tw2 w2;
@@ -209,6 +222,9 @@ __device__ __forceinline__ void frame_inverse_tw(cf (&Z)[21], float (&y)[10], co
   load_tw1(tw, f);
   before_barrier();
   __syncthreads();
+#ifndef RFX_NO_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   after_barrier();
   p1_load_inverse(f.cube, [&tw](int k) { return tw.w[k]; }, y, t.npr);
 }

@@ -48,6 +48,18 @@ __device__ __forceinline__ void mag_issue(MagRegs& m, rsrc_t S, unsigned foff, u
   for (int i = 0; i < 5; ++i) m.s4[i] = ld4<RFX_STREAM_AUX>(S, q16, foff + (unsigned)i * (kQPad * 16u));
   m.tail = ld1<RFX_STREAM_AUX>(S, q16 >> 2, foff + 20u * kQPad * 4u);
 }
+// the same in two parts: the first EARLY 16-byte groups right after the analysis barrier (HBM latency is longer than P3
+// alone), the rest after P2, when its registers have become free
+#ifndef RFX_MAG_SPLIT
+#define RFX_MAG_SPLIT 2
+#endif
+template <int PART>
+__device__ __forceinline__ void mag_issue_part(MagRegs& m, rsrc_t S, unsigned foff, unsigned q16) {
+  constexpr int lo = PART == 0 ? 0 : RFX_MAG_SPLIT, hi = PART == 0 ? RFX_MAG_SPLIT : 5;
+#pragma unroll
+  for (int i = lo; i < hi; ++i) m.s4[i] = ld4<RFX_STREAM_AUX>(S, q16, foff + (unsigned)i * (kQPad * 16u));
+  if (PART == 1) m.tail = ld1<RFX_STREAM_AUX>(S, q16 >> 2, foff + 20u * kQPad * 4u);
+}
 __device__ __forceinline__ float mag_at(const MagRegs& m, int kb) { return kb < 20 ? m.s4[kb >> 2][kb & 3] : m.tail; }
 
 template <int MODE>
@@ -77,7 +89,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   const rsrc_t scl = make_rsrc(g.out_scale, (size_t)g.L * 4);
   const rsrc_t win = make_rsrc(g.win, kWin * 4);
   const unsigned npr4 = (unsigned)t.npr * 4u;
-  const unsigned q16 = threadIdx.x * 16u;  // byte offset of this thread's 16-B slot groups in the streams
+  const unsigned q16 = (unsigned)slot_qp(t.npr) * 16u;  // byte offset of this thread's 16-B slot groups in the streams
 
   float acc[10];
 #pragma unroll
@@ -167,15 +179,11 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
                       RFX_STAMP(1);
                       emit_scaled(pend_blk, pend_val);
                       pend_blk = -1;
-#ifdef RFX_MAG_EARLY
-                      mag_issue(mag, Ssrc, foff, q16);
-#endif
+                      mag_issue_part<0>(mag, Ssrc, foff, q16);
                     },
                     [&] { RFX_STAMP(0); },
                     [&] {
-#ifndef RFX_MAG_EARLY
-                      mag_issue(mag, Ssrc, foff, q16);  // |S| flies under P3 (its 21 registers are not live during P2)
-#endif
+                      mag_issue_part<1>(mag, Ssrc, foff, q16);  // the rest of |S| flies under P3 (its registers are not live during P2)
                     });
       RFX_STAMP(2);
 #ifdef RFX_TIMING
@@ -259,7 +267,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #ifdef RFX_TIMING
   if (g.timing && (threadIdx.x & 63) == 0) {
     const int w = threadIdx.x >> 6;
-    for (int i = 0; i < 12; ++i) g.timing[((size_t)blockIdx.x * 7 + w) * 12 + i] = tacc[i];
+    for (int i = 0; i < 12; ++i) g.timing[((size_t)blockIdx.x * kWaves + w) * 12 + i] = tacc[i];
   }
 #endif
   // ---- flush the parked block and the right halo of the run

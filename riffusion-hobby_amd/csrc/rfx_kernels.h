@@ -59,6 +59,7 @@ struct StftMelArgs {
   const cf* tw2;
   const float* win;
   const float* band_wt;  // [band_rows][Mpad]: weight of filter m on its i-th bin (band_lo[m] + i), zero past its end
+  const int* band_addr;  // [band_rows][Mpad]: LDS float index (2 * cube_at(k1, ka, 0) + kb) of that bin's primary slot
   const int* band_lo;    // [Mpad] first bin of filter m's band (padding filters: 0)
   const int* band_len;   // [Mpad] bins in filter m's band (padding filters: 0)
   int B, T, Lw, frames_per_block;

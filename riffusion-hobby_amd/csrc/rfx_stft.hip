@@ -122,8 +122,11 @@ __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
     cf R[21];
     frame_forward(u, R, f, t, [] {});
     const size_t fbase = ((size_t)clip * a.T + fr) * kFrameStride;
-    const int q = threadIdx.x;  // padded owner index
-    if (a.mag) {  // the padding lane of each wave stores zeros (keeps the mel GEMM free of garbage)
+    // padded owner index of this thread's slots; seven idle lanes store zeros to the padding positions 63, 127, ...
+    // (keeps the mel GEMM free of garbage)
+    const bool store = t.active || t.pad >= 0;
+    const int q = t.active ? slot_qp(t.npr) : 64 * t.pad + 63;
+    if (a.mag && store) {
       float m[21];
 #pragma unroll
       for (int kb = 0; kb < 21; ++kb) m[kb] = t.active ? sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im)) : 0.f;
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
       for (int i = 0; i < 5; ++i) d4[i * kQPad + q] = float4{m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]};
       a.mag[fbase + 20 * kQPad + q] = m[20];
     }
-    if (a.spec) {
+    if (a.spec && store) {
       if (!t.active) {
 #pragma unroll
         for (int kb = 0; kb < 21; ++kb) R[kb] = cf{0.f, 0.f};
@@ -148,8 +151,8 @@ __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
 }
 
 // ---- fused forward path (replaces Spectrogram(power=None) -> abs -> MelScale, spectrogram_converter.py:165-185):
-// the frame engine as above; the magnitudes of the frame are then parked in LDS in BIN order (the cube is free once
-// P3 has read it) and every thread forms the mel amplitudes of one or two filters as the banded dot product
+// the frame engine as above; the magnitudes of the frame are then parked in LDS (each thread's 21 in the cube
+// elements it has just consumed) and every thread forms the mel amplitudes of one or two filters as the banded dot product
 //     mel[m] = sum_{i < band_len[m]} fb[band_lo[m] + i][m] * |X[band_lo[m] + i]|
 // i.e. the reference's `|X|^T @ fb` with the structural zeros of the triangular filterbank left out (7 976 of its
 // 4.5 M products for the default bank), summed in increasing bin order.  The 1.2 GB magnitude stream and the dense
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
   const ThreadId t = thread_id();
   const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
   const float* __restrict__ winp = a.win + t.npr;
-  float* magb = reinterpret_cast<float*>(smem);  // [f_hi - f_lo] magnitudes in bin order, aliases the cube
+  float* magb = reinterpret_cast<float*>(smem);  // float view of the cube: slot (k1, ka, kb) -> magb[2 * cube_at(k1, ka, 0) + kb]
   __syncthreads();
 
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
@@ -168,12 +171,11 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
   const int f1 = min(a.T, f0 + a.frames_per_block);
   const float* __restrict__ x = a.wave + (size_t)clip * a.Lw;
 
-  // the (up to two) filters of this thread: m0 = threadIdx, m1 = threadIdx + 448; waves walk bands of similar length
+  // the (up to two) filters of this thread: m0 = threadIdx, m1 = threadIdx + kThreads; waves walk bands of similar length
   const int m0 = threadIdx.x, m1 = threadIdx.x + kThreads;
   const bool has0 = m0 < a.M, has1 = m1 < a.M;
-  const int lo0 = has0 ? a.band_lo[m0] - a.f_lo : 0, n0 = has0 ? a.band_len[m0] : 0;
-  const int lo1 = has1 ? a.band_lo[m1] - a.f_lo : 0, n1 = has1 ? a.band_len[m1] : 0;
-  const int nb = a.f_hi - a.f_lo;
+  const int n0 = has0 ? a.band_len[m0] : 0;
+  const int n1 = has1 ? a.band_len[m1] : 0;
   float w10[10];
 #pragma unroll
   for (int j = 0; j < 10; ++j) w10[j] = winp[j * kHop];
@@ -187,39 +189,44 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
     }
     cf R[21];
     frame_forward(u, R, f, t, [] {});
-    __syncthreads();  // every wave is done reading the cube: its memory now holds the magnitudes in bin order
+    // P3 read exactly the 21 cube elements (k1, ka, 0..20) that only this thread touches: their memory takes the
+    // thread's 21 magnitudes right away (no barrier, no bank-conflicted scatter); `band_addr` tells the mel threads where
+    // the bins of their filter ended up
     if (t.active) {
+      float* own = magb + 2 * cube_at(t.k1, t.idx, 0);
 #pragma unroll
-      for (int kb = 0; kb < 21; ++kb) {
-        const int k = t.k1 + 40 * (t.idx + 21 * kb);
-        const int bin = k > kNfft / 2 ? kNfft - k : k;
-        // a bin stored twice (k mod 40 in {0, 20}) is written by its primary slot only
-        const bool primary = k <= kNfft / 2 || (t.k1 != 0 && t.k1 != 20);
-        if (primary && bin >= a.f_lo && bin < a.f_hi)
-          magb[bin - a.f_lo] = sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
-      }
+      for (int kb = 0; kb < 21; ++kb) own[kb] = sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
     }
     __syncthreads();
     {
-      // eight weights / magnitudes in flight per step (the table is zero-padded to a multiple of eight rows and the
-      // magnitude index is clamped, so the tail multiplies finite values by zero); bins are summed in increasing order
-      // the weights of step i+1 are requested before step i is summed (L2 latency hidden behind the LDS reads + FMAs)
-      auto band_dot = [&](int m, int lo, int n) {
+      // eight weights / addresses in flight per step (tables zero-padded to a multiple of eight rows: the tail multiplies
+      // a finite magnitude by zero); the next step's are requested before the current eight are summed; bins are summed
+      // in increasing order
+      auto band_dot = [&](int m, int n) {
         const float* __restrict__ wt = a.band_wt + m;
+        const int* __restrict__ ad = a.band_addr + m;
         float s = 0.f;
         float wn[8];
+        int an[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wn[j] = wt[(size_t)j * a.Mpad];
+        for (int j = 0; j < 8; ++j) {
+          wn[j] = wt[(size_t)j * a.Mpad];
+          an[j] = ad[(size_t)j * a.Mpad];
+        }
         for (int i = 0; i < n; i += 8) {
           float w[8], v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = wn[j];
+          for (int j = 0; j < 8; ++j) {
+            w[j] = wn[j];
+            v[j] = magb[an[j]];
+          }
           if (i + 8 < n) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wn[j] = wt[(size_t)(i + 8 + j) * a.Mpad];
+            for (int j = 0; j < 8; ++j) {
+              wn[j] = wt[(size_t)(i + 8 + j) * a.Mpad];
+              an[j] = ad[(size_t)(i + 8 + j) * a.Mpad];
+            }
           }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = magb[min(lo + i + j, nb - 1)];
 #pragma unroll
           for (int j = 0; j < 8; ++j) s = fmaf(w[j], v[j], s);
         }
@@ -228,8 +235,8 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
       // frame-major scratch (512 contiguous floats per frame: whole-line stores); a tiled transpose brings it into the
       // reference's (B, M, T) layout afterwards - 4-byte stores T floats apart cost 10x the bytes in HBM writes
       float* __restrict__ row = a.mel_tm + ((size_t)clip * a.T + fr) * a.Mpad;
-      if (m0 < a.Mpad) row[m0] = has0 ? band_dot(m0, lo0, n0) : 0.f;
-      if (m1 < a.Mpad) row[m1] = has1 ? band_dot(m1, lo1, n1) : 0.f;  // first waves only (M <= 896)
+      if (m0 < a.Mpad) row[m0] = has0 ? band_dot(m0, n0) : 0.f;
+      if (m1 < a.Mpad) row[m1] = has1 ? band_dot(m1, n1) : 0.f;  // first waves only (M <= 896)
     }
     __syncthreads();  // the next frame's P1 overwrites the magnitudes
   }
