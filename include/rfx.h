@@ -84,8 +84,11 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
 /* ---- inverse: torchaudio.transforms.GriffinLim(n_iter, momentum=0.99, rand_init=True, power=1)
  * spectrogram_converter.py:62-73, called at :204.
  * d_mag_slots: magnitudes in slot layout; d_angles0_slots: optional injected initial angles
- * (NULL = draw U[0,1) real/imag per bin from `seed`); d_wave_out: (B, hop*(T-1)) float32. */
+ * (NULL = draw U[0,1) real/imag per bin from `seed`); d_wave_out: (B, rfx_griffinlim_output_samples(plan, T)) float32. */
 size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T);
+/* samples per clip rfx_griffinlim writes for T frames: what torch.istft(center=True, length=None) returns,
+ * hop*(T-1), plus one when n_fft is odd */
+int rfx_griffinlim_output_samples(const rfx_plan* plan, int T);
 int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
                    int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
                    void* stream);

@@ -147,6 +147,10 @@ int rfx_frame_stride(void) { return kFrameStride; }
 int rfx_num_bins(void) { return kBins; }
 int rfx_plan_frame_stride(const rfx_plan* plan) { return plan ? plan->frame_stride : 0; }
 int rfx_plan_is_generic(const rfx_plan* plan) { return plan && plan->generic ? 1 : 0; }
+int rfx_griffinlim_output_samples(const rfx_plan* plan, int T) {
+  if (!plan || T < 1) return 0;
+  return plan->p.hop_length * (T - 1) + (plan->p.n_fft & 1);
+}
 
 int rfx_plan_destroy(rfx_plan* plan);
 
@@ -537,12 +541,15 @@ static void gl_layout(int B, int T, size_t& off_audio, size_t& off_scale, size_t
   total = o;
 }
 
+// torch.istft(center=True, length=None) returns n_fft + hop*(T-1) - 2*(n_fft/2) samples: hop*(T-1), plus one when n_fft is odd
+static int gen_out_len(const GenGeom& g, int T) { return g.hop * (T - 1) + (g.n_fft & 1); }
+
 // generic path: Z and tprev spectra, the windowed frames, one audio estimate
 static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_z, size_t& off_tprev, size_t& off_frames, size_t& off_audio,
                           size_t& total, int& Lpad) {
   const GenGeom& g = plan->gg;
   const size_t nf = (size_t)B * T;
-  Lpad = (int)align_up((size_t)g.hop * (T - 1), 64);
+  Lpad = (int)align_up((size_t)gen_out_len(g, T), 64);
   size_t o = 0;
   off_z = o;
   o += align_up(nf * g.fs * sizeof(cf), 256);
@@ -559,7 +566,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
                           float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream,
                           float* h_launch_ms) {
   const GenGeom& g = plan->gg;
-  const int L = g.hop * (T - 1);
+  const int L = gen_out_len(g, T);
   if (n_iter > 0 && L <= g.n_fft / 2)
     return fail(RFX_ERR_INVALID, "rfx_griffinlim: Padding size should be less than the corresponding input dimension (reflect padding " +
                                  std::to_string(g.n_fft / 2) + " needs more than that many samples)");
@@ -606,7 +613,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     }
     RFX_HIP(launch_gen_istft(it == 0, ia, plan->num_cus, stream));
     const bool last = it == n_iter;
-    RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : audio, g, B, T, last ? (size_t)L : (size_t)Lpad, stream));
+    RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : audio, g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
     if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
   }
   if (h_launch_ms) {

@@ -53,10 +53,20 @@ RFX_HD bool gen_factor(int n, int* radix, int* nstages) {
 
 RFX_HD cf gen_tw(const cf* lo, const cf* hi, int t) { return cmul(hi[t >> 7], lo[t & (kGenTwLo - 1)]); }
 
+// j div Ns for 0 <= j < 2^23 without an integer division (the GPU has none: ~40 instructions): float reciprocal,
+// then one correction step either way.  Exact: j and Ns are exactly representable, the estimate is off by at most one.
+RFX_HD int gen_div(int j, int Ns, float inv_ns) {
+  int q = (int)((float)j * inv_ns);
+  const int r = j - q * Ns;
+  q += (r >= Ns) - (r < 0);
+  return q;
+}
+
 template <int R, bool INV>
-RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, int tstep, const cf* lo, const cf* hi,
+RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, float inv_ns, int tstep, const cf* lo, const cf* hi,
                           const cf (&root)[R]) {
-  const int k = j % Ns;
+  const int jd = gen_div(j, Ns, inv_ns);
+  const int k = j - jd * Ns;
   cf v[R];
   v[0] = in[j];
 #pragma unroll
@@ -91,7 +101,7 @@ RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, int tstep
       y[p] = acc;
     }
   }
-  const int j0 = (j / Ns) * Ns * R + k;
+  const int j0 = jd * Ns * R + k;
 #pragma unroll
   for (int p = 0; p < R; ++p) out[j0 + p * Ns] = y[p];
 }
@@ -99,24 +109,33 @@ RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, int tstep
 template <int R, bool INV>
 RFX_HD void gen_stage_r(const cf* in, cf* out, int nc, int Ns, const cf* lo, const cf* hi, int tid, int nthr) {
   const int m = nc / R, tstep = nc / (Ns * R);
+  const float inv_ns = 1.0f / (float)Ns;
   cf root[R];
 #pragma unroll
   for (int t = 0; t < R; ++t) root[t] = gen_tw(lo, hi, t * m);  // exp(-2 pi i t / R)
-  for (int j = tid; j < m; j += nthr) gen_butterfly<R, INV>(in, out, j, m, Ns, tstep, lo, hi, root);
+  for (int j = tid; j < m; j += nthr) gen_butterfly<R, INV>(in, out, j, m, Ns, inv_ns, tstep, lo, hi, root);
 }
 
-// one Stockham pass, the share of thread `tid` of `nthr`
-template <bool INV>
+// one Stockham pass, the share of thread `tid` of `nthr`.  MAXR is the largest radix the caller's geometry uses: the
+// kernels are instantiated per class (5, 7, 13) so that a 48 kHz plan (radices 4, 2, 3, 5) is not compiled with the
+// register footprint of the O(R^2) radix-13 butterfly (it spilled 131 VGPRs when every radix shared one kernel).
+template <bool INV, int MAXR = 13>
 RFX_HD void gen_stage(const cf* in, cf* out, int nc, int Ns, int R, const cf* lo, const cf* hi, int tid, int nthr) {
   switch (R) {
     case 2: gen_stage_r<2, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
     case 3: gen_stage_r<3, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
     case 4: gen_stage_r<4, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
     case 5: gen_stage_r<5, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
-    case 7: gen_stage_r<7, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
-    case 11: gen_stage_r<11, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
-    default: gen_stage_r<13, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    case 7: if (MAXR >= 7) gen_stage_r<7, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    case 11: if (MAXR >= 11) gen_stage_r<11, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
+    default: if (MAXR >= 13) gen_stage_r<13, INV>(in, out, nc, Ns, lo, hi, tid, nthr); break;
   }
+}
+// the class a radix list needs
+RFX_HD int gen_radix_class(const int* radix, int nstages) {
+  int mx = 0;
+  for (int i = 0; i < nstages; ++i) mx = radix[i] > mx ? radix[i] : mx;
+  return mx <= 5 ? 5 : mx <= 7 ? 7 : 13;
 }
 
 // ---- real <-> packed-complex split.  Z: the nc-point complex spectrum (LDS), lo2/hi2: two-level table of
@@ -128,24 +147,28 @@ RFX_HD cf gen_split_forward(const GenGeom& g, const cf* Z, const cf* lo2, const 
   const cf p = cmul(gen_tw(lo2, hi2, k), d);
   return cf{0.5f * (s.re + p.im), 0.5f * (s.im - p.re)};  // (s - i p) / 2
 }
-// element k (0 <= k < nc) of the complex spectrum whose inverse FFT yields the packed real signal; X(k) fetches bin k of
-// the one-sided spectrum.  Like torch.istft's irfft (pocketfft c2r) the imaginary parts of bins 0 and n_fft/2 are ignored.
-template <class XF>
-RFX_HD cf gen_split_inverse(const GenGeom& g, XF X, const cf* lo2, const cf* hi2, int k) {
+// element k (0 <= k < nc) of the complex spectrum whose inverse FFT yields the packed real signal, from the one-sided
+// bins it is made of: even n_fft: xa = X[k], xb = X[nc - k]; odd n_fft: xa = X[k] (k <= (n_fft-1)/2) or X[n_fft - k], xb unused.
+// Like torch.istft's irfft (pocketfft c2r) the imaginary parts of bins 0 and n_fft/2 are ignored.
+RFX_HD cf gen_split_inverse_vals(const GenGeom& g, cf xa, cf xb, const cf* lo2, const cf* hi2, int k) {
   if (!g.even) {
-    if (k == 0) return cf{X(0).re, 0.f};
-    if (k <= (g.n_fft - 1) / 2) return X(k);
-    const cf c = X(g.n_fft - k);
-    return cf{c.re, -c.im};
+    if (k == 0) return cf{xa.re, 0.f};
+    return k <= (g.n_fft - 1) / 2 ? xa : cf{xa.re, -xa.im};
   }
-  cf xk = X(k), xc = X(g.nc - k);
   if (k == 0) {
-    xk.im = 0.f;
-    xc.im = 0.f;
+    xa.im = 0.f;
+    xb.im = 0.f;
   }
-  const cf s{xk.re + xc.re, xk.im - xc.im}, d{xk.re - xc.re, xk.im + xc.im};  // X[k] +- conj X[nc-k]
+  const cf s{xa.re + xb.re, xa.im - xb.im}, d{xa.re - xb.re, xa.im + xb.im};  // X[k] +- conj X[nc-k]
   const cf p = cmulc(d, gen_tw(lo2, hi2, k));  // d * exp(+2 pi i k / n_fft)
   return cf{0.5f * (s.re - p.im), 0.5f * (s.im + p.re)};  // (s + i p) / 2
+}
+// which one-sided bins element k needs
+RFX_HD int gen_split_bin_a(const GenGeom& g, int k) { return (g.even || k <= (g.n_fft - 1) / 2) ? k : g.n_fft - k; }
+RFX_HD int gen_split_bin_b(const GenGeom& g, int k) { return g.even ? g.nc - k : 0; }
+template <class XF>
+RFX_HD cf gen_split_inverse(const GenGeom& g, XF X, const cf* lo2, const cf* hi2, int k) {
+  return gen_split_inverse_vals(g, X(gen_split_bin_a(g, k)), X(gen_split_bin_b(g, k)), lo2, hi2, k);
 }
 
 // Griffin-Lim per-bin update of the generic path, op by op as the reference executes it (torchaudio functional.griffinlim,

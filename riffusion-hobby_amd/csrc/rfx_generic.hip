@@ -49,14 +49,14 @@ __device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const Ge
 size_t gen_lds_bytes(const GenGeom& g) { return sizeof(cf) * (2 * (size_t)g.nc + 2 * kGenTwLo + g.nhi + g.nhi2); }
 
 // all passes of the nc-point FFT; data starts in l.a, the result's buffer is returned.  Barriers inside.
-template <bool INV>
+template <bool INV, int MAXR>
 __device__ __forceinline__ cf* gen_fft(const GenGeom& g, const GenLds& l) {
   cf* in = l.a;
   cf* out = l.b;
   int Ns = 1;
   for (int s = 0; s < g.nstages; ++s) {
     __syncthreads();
-    gen_stage<INV>(in, out, g.nc, Ns, g.radix[s], l.lo, l.hi, (int)threadIdx.x, (int)blockDim.x);
+    gen_stage<INV, MAXR>(in, out, g.nc, Ns, g.radix[s], l.lo, l.hi, (int)threadIdx.x, (int)blockDim.x);
     Ns *= g.radix[s];
     cf* t = in;
     in = out;
@@ -69,7 +69,9 @@ __device__ __forceinline__ cf* gen_fft(const GenGeom& g, const GenLds& l) {
 // ---- forward: frame fr of clip b is centred on sample hop*fr of the reflect-padded waveform (torch.stft center=True)
 enum GenStftMode { kGenMag = 0, kGenSpec = 1, kGenGl = 2 };
 
-template <int MODE>
+// (Prefetching the next frame's samples and the epilogue's |S| / tprev into register slots across the passes was tried:
+// 229 -> 245-257 ms per 64 tiles at 48 kHz - the slot arrays spill.  The simple loops below stay.)
+template <int MODE, int MAXR>
 __global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GenGeom& g = a.g;
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
       }
       l.a[n] = cf{v[0], v[1]};
     }
-    const cf* Z = gen_fft<false>(g, l);
+    const cf* Z = gen_fft<false, MAXR>(g, l);
     const size_t base = (size_t)fr * g.fs;
     for (int k = threadIdx.x; k < g.fs; k += blockDim.x) {
       if (k >= g.n_stft) {  // padding of the frame stride: keep it zero
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
 }
 
 // ---- inverse: one-sided spectrum of frame fr -> its win_length windowed samples (irfft scaling folded in)
-template <bool INIT>
+template <bool INIT, int MAXR>
 __global__ void __launch_bounds__(kGenThreads) gen_istft_kernel(GenIstftArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GenGeom& g = a.g;
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_istft_kernel(GenIstftArgs a) 
     };
     __syncthreads();
     for (int k = threadIdx.x; k < g.nc; k += blockDim.x) l.a[k] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
-    const cf* z = gen_fft<true>(g, l);
+    const cf* z = gen_fft<true, MAXR>(g, l);
     float* __restrict__ out = a.frames + (size_t)fr * g.win;
     for (int j = threadIdx.x; j < g.win; j += blockDim.x) {
       const int i = j + g.left;
@@ -224,41 +226,48 @@ static int gen_grid(const GenGeom& g, int num_cus, long long nframes) {
   return (int)(n < nframes ? n : nframes);
 }
 
+// kernels by (mode, radix class)
+using GenStftFn = void (*)(GenStftArgs);
+using GenIstftFn = void (*)(GenIstftArgs);
+template <int MAXR>
+static GenStftFn gen_stft_fn(int mode) {
+  return mode == kGenMag ? gen_stft_kernel<kGenMag, MAXR> : mode == kGenSpec ? gen_stft_kernel<kGenSpec, MAXR> : gen_stft_kernel<kGenGl, MAXR>;
+}
+static GenStftFn gen_stft_fn(const GenGeom& g, int mode) {
+  const int c = gen_radix_class(g.radix, g.nstages);
+  return c == 5 ? gen_stft_fn<5>(mode) : c == 7 ? gen_stft_fn<7>(mode) : gen_stft_fn<13>(mode);
+}
+static GenIstftFn gen_istft_fn(const GenGeom& g, bool init) {
+  const int c = gen_radix_class(g.radix, g.nstages);
+  if (c == 5) return init ? gen_istft_kernel<true, 5> : gen_istft_kernel<false, 5>;
+  if (c == 7) return init ? gen_istft_kernel<true, 7> : gen_istft_kernel<false, 7>;
+  return init ? gen_istft_kernel<true, 13> : gen_istft_kernel<false, 13>;
+}
+
 hipError_t prepare_generic_kernels(const GenGeom& g) {
   const int lds = (int)gen_lds_bytes(g);
   hipError_t e;
-#define RFX_SET(k) if ((e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e
-  RFX_SET(gen_stft_kernel<kGenMag>);
-  RFX_SET(gen_stft_kernel<kGenSpec>);
-  RFX_SET(gen_stft_kernel<kGenGl>);
-  RFX_SET(gen_istft_kernel<true>);
-  RFX_SET(gen_istft_kernel<false>);
-#undef RFX_SET
+  for (int mode = 0; mode < 3; ++mode)
+    if ((e = hipFuncSetAttribute((const void*)gen_stft_fn(g, mode), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  for (int init = 0; init < 2; ++init)
+    if ((e = hipFuncSetAttribute((const void*)gen_istft_fn(g, init != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
   return hipSuccess;
 }
 
 hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream) {
   const int grid = gen_grid(a.g, num_cus, (long long)a.B * a.T);
-  const size_t lds = gen_lds_bytes(a.g);
-  switch (mode) {
-    case kGenMag: hipLaunchKernelGGL(gen_stft_kernel<kGenMag>, dim3(grid), dim3(kGenThreads), lds, stream, a); break;
-    case kGenSpec: hipLaunchKernelGGL(gen_stft_kernel<kGenSpec>, dim3(grid), dim3(kGenThreads), lds, stream, a); break;
-    default: hipLaunchKernelGGL(gen_stft_kernel<kGenGl>, dim3(grid), dim3(kGenThreads), lds, stream, a); break;
-  }
+  hipLaunchKernelGGL(gen_stft_fn(a.g, mode), dim3(grid), dim3(kGenThreads), gen_lds_bytes(a.g), stream, a);
   return hipGetLastError();
 }
 
 hipError_t launch_gen_istft(bool init, const GenIstftArgs& a, int num_cus, hipStream_t stream) {
   const int grid = gen_grid(a.g, num_cus, (long long)a.B * a.T);
-  const size_t lds = gen_lds_bytes(a.g);
-  if (init) hipLaunchKernelGGL(gen_istft_kernel<true>, dim3(grid), dim3(kGenThreads), lds, stream, a);
-  else hipLaunchKernelGGL(gen_istft_kernel<false>, dim3(grid), dim3(kGenThreads), lds, stream, a);
+  hipLaunchKernelGGL(gen_istft_fn(a.g, init), dim3(grid), dim3(kGenThreads), gen_lds_bytes(a.g), stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, size_t out_stride,
+hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
                            hipStream_t stream) {
-  const int L = g.hop * (T - 1);
   hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, win, out, g, B, T, L, out_stride);
   return hipGetLastError();
 }

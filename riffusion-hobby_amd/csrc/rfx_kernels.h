@@ -157,8 +157,8 @@ hipError_t prepare_generic_kernels(const GenGeom& g);
 size_t gen_lds_bytes(const GenGeom& g);
 hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream);  // mode 0 mag, 1 spec, 2 Griffin-Lim
 hipError_t launch_gen_istft(bool init, const GenIstftArgs& a, int num_cus, hipStream_t stream);
-hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, size_t out_stride,
-                           hipStream_t stream);
+hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
+                           hipStream_t stream);  // L output samples per clip
 hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_mel(const float* mag, float* mel_tm, const float* band_wt, const int* band_lo, const int* band_len, long long nframes,

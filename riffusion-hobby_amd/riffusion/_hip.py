@@ -64,6 +64,7 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_unpack_complex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rfx_stft": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rfx_griffinlim_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "rfx_griffinlim_output_samples": (c_int, [c_void_p, c_int]),
     "rfx_griffinlim": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p],
@@ -301,7 +302,7 @@ class Plan:
             workspace = self._chk(workspace)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=mag_slots.device)
-        out = torch.empty((B, self.hop_length * (Tn - 1)), dtype=torch.float32, device=mag_slots.device)
+        out = torch.empty((B, self.lib.rfx_griffinlim_output_samples(self.handle, Tn)), dtype=torch.float32, device=mag_slots.device)
         if launch_ms is not None:  # ctypes float array of n_iter + 1 entries, filled after a stream sync
             check(
                 self.lib.rfx_griffinlim_timed(

@@ -137,7 +137,7 @@ class SpectrogramImageConverter:
                 outs.append(wave.reshape(b - a, C, -1) if return_waveform else plan.pcm16(wave, channels=C, normalize=True)[0])
             if outs:
                 return torch.cat(outs, dim=0)
-            L = self.p.hop_length * (imgs.shape[2] - 1)  # a rank with an empty shard still joins the gather
+            L = plan.lib.rfx_griffinlim_output_samples(plan.handle, int(imgs.shape[2]))  # a rank with an empty shard still joins the gather
             return torch.empty((0, C, L) if return_waveform else (0, L, C),
                                dtype=torch.float32 if return_waveform else torch.int16, device=plan.device)
 

@@ -168,3 +168,57 @@ def test_unsupported_fft_length_is_refused_with_a_reason():
     assert p.n_fft == 17028
     with pytest.raises(_hip.RfxError, match="prime factor above 13"):
         _plan(p)
+
+
+@pytest.mark.parametrize(
+    "kw",
+    [
+        dict(sample_rate=48000, max_frequency=20000, stereo=True, num_frequencies=256),  # 8000 active bins: general SGD kernel
+        dict(sample_rate=44100, padded_duration_ms=300, window_duration_ms=50),           # n_fft 13230 = 2 * 3^3 * 5 * 7^2, win 2205
+        dict(sample_rate=34650, padded_duration_ms=100, window_duration_ms=100, max_frequency=8000),  # ODD n_fft 3465 = win
+        dict(sample_rate=8000, max_frequency=4000),                                       # n_fft 3200 = 2^7 * 5^2
+    ],
+)
+def test_other_parameter_sets_end_to_end(O, kw):
+    """Stage by stage against the oracle on less common parameter sets (odd n_fft, win == n_fft, window much shorter than the
+    padding, a filterbank that covers 8000 bins), then the whole torch-level seam with injected initial values."""
+    from riffusion.spectrogram_converter import SpectrogramConverter
+
+    p = _params(num_griffin_lim_iters=4, max_mel_iters=30, **kw)
+    op = O.params_from(p)
+    plan = _plan(p)
+    assert plan.generic
+    C, T = (2 if p.stereo else 1), 40
+    wave = synthetic_wave(C, p.hop_length * (T - 1) + 3, seed=p.n_fft)
+    ref = O.stft_complex(wave, op)
+    _, spec, Tn = plan.stft(wave.cuda(), want_mag=False, want_spec=True)
+    assert Tn == ref.shape[-1]
+    err = float((plan.unpack_complex(spec, C, Tn).cpu() - ref).abs().max() / ref.abs().max())
+    mel_ref = O.mel_amplitudes_from_waveform(wave, op)
+    mel = plan.mel_from_waveform(wave.cuda()).cpu()
+    rel_mel = float(torch.linalg.norm(mel - mel_ref) / torch.linalg.norm(mel_ref))
+    g = torch.Generator().manual_seed(1)
+    spec0 = torch.rand(C, Tn, op.n_stft, generator=g)
+    angles0 = torch.rand(C, op.n_stft, Tn, dtype=torch.complex64, generator=g)
+    want = O.waveform_from_mel_amplitudes(mel_ref, op, spec0=spec0, angles0=angles0)
+    conv = SpectrogramConverter(p, device="cuda")
+    got = conv.waveform_from_mel_amplitudes(mel_ref.cuda(), spec0=spec0.cuda(), angles0=angles0.cuda()).cpu()
+    s = snr_db(want, got)
+    print(f"{kw}: n_fft {p.n_fft} win {p.win_length} hop {p.hop_length}: STFT {err:.2e}, mel rel-L2 {rel_mel:.2e}, inverse (SGD-30 + GL-4) {s:.1f} dB")
+    assert err <= 3e-6 and rel_mel <= 1e-4
+    assert got.shape == want.shape and s >= 80.0
+
+
+def test_full_size_round_trip_at_48k():
+    """512-frame clips at 48 kHz: ISTFT(STFT(x)) = x through the generic engine (n_iter = 0 with the true phases)."""
+    p = _params(sample_rate=48000)
+    plan = _plan(p)
+    B, T = 8, 512
+    x = synthetic_wave(B, 480 * (T - 1), seed=5).cuda()
+    mag, X, Tn = plan.stft(x, want_mag=True, want_spec=True)
+    assert Tn == T
+    phase = X / X.abs().clamp_min(1e-30)
+    back = plan.griffinlim(mag, B, T, 0, 0.99, angles0_slots=phase.contiguous())
+    s = snr_db(x, back)
+    print(f"48 kHz STFT -> ISTFT round trip {s:.1f} dB")
+    assert s >= 105.0
