@@ -77,6 +77,22 @@ def relaunch_distributed(n_gpus: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+class stdout_to_stderr:
+    """RCCL prints a start-up banner (version, hostname, library path) straight to file descriptor 1 when a communicator is
+    created; the contract is ONE JSON line on stdout, so fd 1 points at stderr while the process group comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def git_rev(path: str) -> str:
     """Short hash of the last commit that touched `path` (provenance of numbers read from profiles/)."""
     import subprocess
@@ -361,14 +377,16 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if distributed else 0)
     torch.cuda.set_device(dev)
     n_ranks = 1
     if distributed:  # n_gpus = ranks that answered an RCCL all_reduce
-        ones = torch.ones(1, dtype=torch.int32, device=dev)
-        dist.all_reduce(ones)
-        n_ranks = int(ones.item())
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)
+            ones = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(ones)
+            n_ranks = int(ones.item())
+            torch.cuda.synchronize(dev)
         assert n_ranks == world
 
     def finish(out):
