@@ -267,9 +267,10 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
                 fpmc = json.load(fh)
         except Exception:
             fpmc = {}
+        fscale = B / float(fpmc.get("batch_tiles", 64))
         roof = {"kernel": "rfx::stft_mel_kernel", "bound": "hbm", "achieved": round(alg_bytes / (mel_ms * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (mel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "traffic": fpmc.get("hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(mel_ms, 4),
+                "traffic": fpmc.get("hbm_bytes_per_launch") * fscale if fpmc.get("hbm_bytes_per_launch") else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(mel_ms, 4),
                 "dense_equivalent_tflops": round(dense_flop / (mel_ms * 1e-3) / 1e12, 1),
                 "note": "fused framed transform -> |X| -> banded mel projection in one launch: the mel GEMM of the reference (4.6 of its "
                         "4.94 GFLOP per tile) multiplies a banded filterbank (7 976 non-zeros of 4.5 M) and is evaluated as such on chip, "
@@ -277,6 +278,7 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
                         "reference's dense flop count (label: dense-equivalent, SURVEY 8(d)); `binding` is the resource that does"}
         valu = fpmc.get("SQ_INSTS_VALU_per_launch")
         if valu:
+            valu *= fscale
             got = valu / (mel_ms * 1e-3) / 1e9
             roof["binding"] = {"bound": "valu", "unit": "G wave-instructions/s", "wave_instructions_per_launch": valu, "achieved": round(got, 1),
                                "peak": 1228.8, "frac": round(got / 1228.8, 4), "sustained_peak": round(1024 / 1.13, 1),
@@ -455,7 +457,10 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         pmc = pmc_summary()
         pmc_src = "profiles/gl_iter_pmc_latest.json"
+        # the counters were collected at the headline batch; per-launch figures scale with the frames a launch processes
+        pmc_scale = (B * T) / float(pmc.get("batch_tiles", 64) * pmc.get("frames_per_tile", 512))
         traffic = pmc.get("hbm_bytes_per_launch")
+        traffic = traffic * pmc_scale if traffic else traffic
         roofline = {
             "kernel": "rfx::gl_iter_kernel<2>",
             "bound": "hbm",
@@ -481,6 +486,7 @@ def main():
             roofline["actual_hbm_gbs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
             roofline["actual_hbm_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         valu = pmc.get("SQ_INSTS_VALU_per_launch")
+        valu = valu * pmc_scale if valu else valu
         if valu:
             # spec issue rate (MI355X_MICROARCH.md): 1024 SIMD-32 units, a wave64 fp32 instruction every 2 cycles at 2.4 GHz
             spec_ginstr = 1024 * 2.4 / 2

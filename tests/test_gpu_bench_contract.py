@@ -1,0 +1,59 @@
+"""
+bench.py's output contract, exercised on the GPU with a small batch: exactly ONE line on stdout, valid JSON with the keys the
+driver reads, the `roofline` / `forward` objects, and the same through a torch.distributed.run launch (RCCL, one rank) - whose
+communicator start-up banner must not reach stdout.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config"}
+
+
+def _one_json_line(proc):
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {[ln[:60] for ln in lines]}"
+    return json.loads(lines[0])
+
+
+def test_headline_line_small_batch():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "4", "--iters", "32",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    d = _one_json_line(p)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["unit"] == "tiles/s" and d["higher_is_better"] is True
+    assert d["metric"] == "spectrogram_tiles_per_sec_griffinlim32" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["binding"]["bound"] == "valu" and 0 < r["binding"]["frac"] < 1.2 and "source" in r["from_profiles"]
+    f = d["forward"]
+    assert f["unit"] == "images/s" and f["value"] > 0 and f["roofline"]["kernel"] == "rfx::stft_mel_kernel"
+    assert {"image_decode_ms", "inverse_mel_ms", "griffinlim_ms", "pcm16_ms"} <= set(d["stages"])
+
+
+def test_distributed_launch_one_rank_keeps_stdout_clean():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-forward"]
+    d = _one_json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=600))
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4
+
+
+def test_sharded_stereo_workload_small():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "decode-stereo64", "--global-clips", "4", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600)
+    d = _one_json_line(p)
+    assert d["scaling"] == "strong" and d["config"]["griffin_lim_iters"] == 64 and d["config"]["global_batch"] == 4 and d["value"] > 0
