@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(kThreads) stft_kernel(StftArgs a) {
 // i.e. the reference's `|X|^T @ fb` with the structural zeros of the triangular filterbank left out (7 976 of its
 // 4.5 M products for the default bank), summed in increasing bin order.  The 1.2 GB magnitude stream and the dense
 // GEMM of the unfused path disappear; only (B, M, T) floats are written.
-__global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
+__global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) {  // 128 VGPRs: two workgroups per CU (it took 171 = one per CU without the bound)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ThreadId t = thread_id();
   const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
@@ -200,9 +200,17 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
     __syncthreads();
     {
       // eight weights / addresses in flight per step (tables zero-padded to a multiple of eight rows: the tail multiplies
-      // a finite magnitude by zero); the next step's are requested before the current eight are summed; bins are summed
-      // in increasing order
-      auto band_dot = [&](int m, int n) {
+      // a finite magnitude by zero; padding filters have length 0); the next step's are requested before the current eight
+      // are summed; bins are summed in increasing order
+      // frame-major scratch (512 contiguous floats per frame: whole-line stores); a tiled transpose brings it into the
+      // reference's (B, M, T) layout afterwards - 4-byte stores T floats apart cost 10x the bytes in HBM writes
+      float* __restrict__ row = a.mel_tm + ((size_t)clip * a.T + fr) * a.Mpad;
+      // one code path for the (up to) two filters of a thread, run one after the other: its register arrays exist once
+#pragma unroll 1
+      for (int which = 0; which < 2; ++which) {
+        const int m = which ? m1 : m0;
+        if (m >= a.Mpad) break;  // wave-uniform: only the first wave(s) carry a second filter
+        const int n = which ? n1 : n0;
         const float* __restrict__ wt = a.band_wt + m;
         const int* __restrict__ ad = a.band_addr + m;
         float s = 0.f;
@@ -213,6 +221,7 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
           wn[j] = wt[(size_t)j * a.Mpad];
           an[j] = ad[(size_t)j * a.Mpad];
         }
+#pragma unroll 1
         for (int i = 0; i < n; i += 8) {
           float w[8], v[8];
 #pragma unroll
@@ -230,13 +239,8 @@ __global__ void __launch_bounds__(kThreads) stft_mel_kernel(StftMelArgs a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) s = fmaf(w[j], v[j], s);
         }
-        return s;
-      };
-      // frame-major scratch (512 contiguous floats per frame: whole-line stores); a tiled transpose brings it into the
-      // reference's (B, M, T) layout afterwards - 4-byte stores T floats apart cost 10x the bytes in HBM writes
-      float* __restrict__ row = a.mel_tm + ((size_t)clip * a.T + fr) * a.Mpad;
-      if (m0 < a.Mpad) row[m0] = has0 ? band_dot(m0, n0) : 0.f;
-      if (m1 < a.Mpad) row[m1] = has1 ? band_dot(m1, n1) : 0.f;  // first waves only (M <= 896)
+        row[m] = m < a.M ? s : 0.f;
+      }
     }
     __syncthreads();  // the next frame's P1 overwrites the magnitudes
   }
