@@ -119,8 +119,8 @@ def cpu_baseline(iters: int, threads_cap: int = 16, min_seconds: float = 10.0, m
     The oracle (a torch-CPU port of the reference's torchaudio path) on the host cores, on a BOUNDED
     sample of the same workload: whole synthetic mono 512x512 tiles, one after the other (one call of
     the reference per tile), until at least `min_seconds` of CPU work have been timed (at most
-    `max_tiles` tiles).  Threads are capped: torch's CPU kernels degrade badly when a 256-thread host
-    is oversubscribed (the unbounded run took 424 s for one tile).
+    `max_tiles` tiles).  Threads are capped at 16, the fastest setting measured on the GPU box (one tile: 5.4 / 4.4 / 5.8 /
+    9.5 / 17.6 s on 8 / 16 / 32 / 64 / 128 threads, profiles/r02_cpu_oracle_thread_scaling.txt; all 256: 424 s).
     """
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import riffusion_oracle as O  # checker / reported baseline only
