@@ -25,6 +25,12 @@ constexpr int kGenMaxStages = 16;
 constexpr int kGenTwLo = 128;       // entries of the low twiddle table
 constexpr int kGenMaxNc = 10000;    // two LDS buffers of nc complex numbers + tables must fit 160 KiB
 
+// LDS position of element i of an FFT buffer.  (A pad element after every 32 - i + (i >> 5) - removes the 4- to 16-way
+// bank conflicts of the early Stockham passes, 54 % of all LDS cycles by PMC; measured: no gain at 48 kHz, 7 % slower at
+// 22.05 kHz - the kernels wait on barriers and dependent LDS round trips, not on LDS bandwidth.  Identity kept.)
+RFX_HD int gen_pad(int i) { return i; }
+RFX_HD int gen_buf_elems(int nc) { return nc; }
+
 struct GenGeom {
   int n_fft, win, hop, n_stft;
   int nc;       // length of the complex FFT: n_fft/2 (even n_fft) or n_fft (odd)
@@ -68,11 +74,12 @@ RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, float inv
   const int jd = gen_div(j, Ns, inv_ns);
   const int k = j - jd * Ns;
   cf v[R];
-  v[0] = in[j];
+  v[0] = in[gen_pad(j)];
 #pragma unroll
   for (int q = 1; q < R; ++q) {
     const cf w = gen_tw(lo, hi, q * k * tstep);  // q * k * tstep < nc
-    v[q] = INV ? cmulc(in[j + q * m], w) : cmul(in[j + q * m], w);
+    const cf x = in[gen_pad(j + q * m)];
+    v[q] = INV ? cmulc(x, w) : cmul(x, w);
   }
   cf y[R];
   if (R == 2) {
@@ -87,6 +94,33 @@ RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, float inv
     y[2] = cf{a.re - c.re, a.im - c.im};
     y[1] = cf{b.re + md.re, b.im + md.im};
     y[3] = cf{b.re - md.re, b.im - md.im};
+  } else if (R == 3) {
+    cf a = v[0], b = v[1], c = v[2];
+    dft3<INV>(a, b, c);
+    y[0] = a;
+    y[1] = b;
+    y[2] = c;
+  } else if (R == 5) {
+    // X0 = x0 + s1 + s2;  X1,4 = a1 -+ i b1;  X2,3 = a2 -+ i b2  (forward; the inverse swaps the signs)
+    constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;  // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;   // sin(2 pi / 5), sin(4 pi / 5)
+    const cf p1{v[1].re + v[4].re, v[1].im + v[4].im}, m1{v[1].re - v[4].re, v[1].im - v[4].im};
+    const cf p2{v[2].re + v[3].re, v[2].im + v[3].im}, m2{v[2].re - v[3].re, v[2].im - v[3].im};
+    const cf a1{fmaf(c2, p2.re, fmaf(c1, p1.re, v[0].re)), fmaf(c2, p2.im, fmaf(c1, p1.im, v[0].im))};
+    const cf a2{fmaf(c1, p2.re, fmaf(c2, p1.re, v[0].re)), fmaf(c1, p2.im, fmaf(c2, p1.im, v[0].im))};
+    const cf b1{fmaf(s2, m2.re, s1 * m1.re), fmaf(s2, m2.im, s1 * m1.im)};
+    const cf b2{fmaf(-s1, m2.re, s2 * m1.re), fmaf(-s1, m2.im, s2 * m1.im)};
+    y[0] = cf{v[0].re + p1.re + p2.re, v[0].im + p1.im + p2.im};
+    const cf lo1{a1.re + b1.im, a1.im - b1.re}, hi1{a1.re - b1.im, a1.im + b1.re};  // a - i b, a + i b
+    const cf lo2{a2.re + b2.im, a2.im - b2.re}, hi2{a2.re - b2.im, a2.im + b2.re};
+    y[1] = INV ? hi1 : lo1;
+    y[4] = INV ? lo1 : hi1;
+    y[2] = INV ? hi2 : lo2;
+    y[3] = INV ? lo2 : hi2;
+  } else if (R == 7) {
+    cf x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3], x4 = v[4], x5 = v[5], x6 = v[6];
+    dft7<INV>(x0, x1, x2, x3, x4, x5, x6);
+    y[0] = x0; y[1] = x1; y[2] = x2; y[3] = x3; y[4] = x4; y[5] = x5; y[6] = x6;
   } else {
 #pragma unroll
     for (int p = 0; p < R; ++p) {
@@ -103,7 +137,7 @@ RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, float inv
   }
   const int j0 = jd * Ns * R + k;
 #pragma unroll
-  for (int p = 0; p < R; ++p) out[j0 + p * Ns] = y[p];
+  for (int p = 0; p < R; ++p) out[gen_pad(j0 + p * Ns)] = y[p];
 }
 
 template <int R, bool INV>
@@ -141,8 +175,8 @@ RFX_HD int gen_radix_class(const int* radix, int nstages) {
 // ---- real <-> packed-complex split.  Z: the nc-point complex spectrum (LDS), lo2/hi2: two-level table of
 // exp(-2 pi i k / n_fft).  Returns bin k (0 <= k <= n_fft/2) of the real FFT.
 RFX_HD cf gen_split_forward(const GenGeom& g, const cf* Z, const cf* lo2, const cf* hi2, int k) {
-  if (!g.even) return Z[k];
-  const cf zk = Z[k == g.nc ? 0 : k], zc = Z[k == 0 ? 0 : g.nc - k];
+  if (!g.even) return Z[gen_pad(k)];
+  const cf zk = Z[gen_pad(k == g.nc ? 0 : k)], zc = Z[gen_pad(k == 0 ? 0 : g.nc - k)];
   const cf s{zk.re + zc.re, zk.im - zc.im}, d{zk.re - zc.re, zk.im + zc.im};  // Z[k] +- conj Z[nc-k]
   const cf p = cmul(gen_tw(lo2, hi2, k), d);
   return cf{0.5f * (s.re + p.im), 0.5f * (s.im - p.re)};  // (s - i p) / 2
@@ -171,12 +205,12 @@ RFX_HD cf gen_split_inverse(const GenGeom& g, XF X, const cf* lo2, const cf* hi2
   return gen_split_inverse_vals(g, X(gen_split_bin_a(g, k)), X(gen_split_bin_b(g, k)), lo2, hi2, k);
 }
 
-// Griffin-Lim per-bin update of the generic path, op by op as the reference executes it (torchaudio functional.griffinlim,
-// SURVEY App. A.5): a = rebuilt - m * tprev ; angles = a / (|a| + 1e-16) ; next = S * angles.  IEEE sqrt / divide.
+// Griffin-Lim per-bin update of the generic path, in the reference's op order (torchaudio functional.griffinlim,
+// SURVEY App. A.5): a = rebuilt - m * tprev ; angles = a / (|a| + 1e-16) ; next = S * angles.  The normalisation is
+// gl_project of rfx_core.h (one v_rsq_f32 on the device: the IEEE sqrt + two divisions it replaces were 30 % of this
+// kernel's instructions; exact sqrt / divide on the host).
 RFX_HD cf gen_gl_update(cf rebuilt, cf tprev, float mom, float S) {
-  const cf a{rebuilt.re - tprev.re * mom, rebuilt.im - tprev.im * mom};
-  const float den = sqrtf(a.re * a.re + a.im * a.im) + 1e-16f;
-  return cf{S * (a.re / den), S * (a.im / den)};
+  return gl_project(cf{rebuilt.re - tprev.re * mom, rebuilt.im - tprev.im * mom}, S);
 }
 
 }  // namespace rfx

@@ -10,7 +10,7 @@
 //     rebuilt = STFT(x_k)                  gen_stft_kernel<GL>, whose epilogue does the per-bin update
 //     Z_{k+1} = S * normalise(rebuilt - m * tprev),  tprev <- rebuilt
 // 36 B per bin and iteration (|S| 4 + tprev 8 + 8 + Z 8 + 8) plus the windowed frames.  Slower than the specialised
-// path by design (measured: 4-7x per tile), bit-reproducible (no atomics), same entry points.
+// path by design (measured: 3-6x per tile), bit-reproducible (no atomics), same entry points.
 #include <hip/hip_runtime.h>
 
 #include "rfx_gen_core.h"
@@ -32,8 +32,8 @@ struct GenLds {
 __device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const GenTables& tb) {
   GenLds l;
   l.a = reinterpret_cast<cf*>(smem);
-  l.b = l.a + g.nc;
-  l.lo = l.b + g.nc;
+  l.b = l.a + gen_buf_elems(g.nc);
+  l.lo = l.b + gen_buf_elems(g.nc);
   l.hi = l.lo + kGenTwLo;
   l.lo2 = l.hi + g.nhi;
   l.hi2 = l.lo2 + kGenTwLo;
@@ -46,7 +46,7 @@ __device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const Ge
   return l;
 }
 
-size_t gen_lds_bytes(const GenGeom& g) { return sizeof(cf) * (2 * (size_t)g.nc + 2 * kGenTwLo + g.nhi + g.nhi2); }
+size_t gen_lds_bytes(const GenGeom& g) { return sizeof(cf) * (2 * (size_t)gen_buf_elems(g.nc) + 2 * kGenTwLo + g.nhi + g.nhi2); }
 
 // all passes of the nc-point FFT; data starts in l.a, the result's buffer is returned.  Barriers inside.
 template <bool INV, int MAXR>
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
         const int j = i - g.left;              // position inside the window
         if (j >= 0 && j < g.win) v[e] = x[reflect_index(g.hop * t + i - half, a.Lw)] * a.tb.win[j];
       }
-      l.a[n] = cf{v[0], v[1]};
+      l.a[gen_pad(n)] = cf{v[0], v[1]};
     }
     const cf* Z = gen_fft<false, MAXR>(g, l);
     const size_t base = (size_t)fr * g.fs;
@@ -134,12 +134,13 @@ __global__ void __launch_bounds__(kGenThreads) gen_istft_kernel(GenIstftArgs a) 
       return cf{s * ang.re, s * ang.im};
     };
     __syncthreads();
-    for (int k = threadIdx.x; k < g.nc; k += blockDim.x) l.a[k] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
+    for (int k = threadIdx.x; k < g.nc; k += blockDim.x) l.a[gen_pad(k)] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
     const cf* z = gen_fft<true, MAXR>(g, l);
     float* __restrict__ out = a.frames + (size_t)fr * g.win;
     for (int j = threadIdx.x; j < g.win; j += blockDim.x) {
       const int i = j + g.left;
-      const float v = g.even ? ((i & 1) ? z[i >> 1].im : z[i >> 1].re) : z[i].re;
+      const cf zz = z[gen_pad(g.even ? i >> 1 : i)];
+      const float v = (g.even && (i & 1)) ? zz.im : zz.re;
       out[j] = v * scale * a.tb.win[j];
     }
   }

@@ -59,8 +59,8 @@ int emu_gen_factor(int n_fft, int* radix_out) {
 int emu_gen_rfft(int n_fft, const float* frame, float* out, int nthr) {
   GenGeom g; Tables t;
   if (!make_geom(n_fft, n_fft, 1, g, t)) return -1;
-  std::vector<cf> a(g.nc), b(g.nc);
-  for (int n = 0; n < g.nc; ++n) a[n] = g.even ? cf{frame[2 * n], frame[2 * n + 1]} : cf{frame[n], 0.f};
+  std::vector<cf> a(gen_buf_elems(g.nc)), b(gen_buf_elems(g.nc));
+  for (int n = 0; n < g.nc; ++n) a[gen_pad(n)] = g.even ? cf{frame[2 * n], frame[2 * n + 1]} : cf{frame[n], 0.f};
   const cf* Z = run_fft<false>(g, t, a.data(), b.data(), nthr);
   for (int k = 0; k < g.n_stft; ++k) {
     const cf X = gen_split_forward(g, Z, t.lo2.data(), t.hi2.data(), k);
@@ -73,12 +73,15 @@ int emu_gen_rfft(int n_fft, const float* frame, float* out, int nthr) {
 int emu_gen_irfft(int n_fft, const float* spec, float* out, int nthr) {
   GenGeom g; Tables t;
   if (!make_geom(n_fft, n_fft, 1, g, t)) return -1;
-  std::vector<cf> a(g.nc), b(g.nc);
+  std::vector<cf> a(gen_buf_elems(g.nc)), b(gen_buf_elems(g.nc));
   auto X = [&](int k) { return cf{spec[2 * k], spec[2 * k + 1]}; };
-  for (int k = 0; k < g.nc; ++k) a[k] = gen_split_inverse(g, X, t.lo2.data(), t.hi2.data(), k);
+  for (int k = 0; k < g.nc; ++k) a[gen_pad(k)] = gen_split_inverse(g, X, t.lo2.data(), t.hi2.data(), k);
   const cf* z = run_fft<true>(g, t, a.data(), b.data(), nthr);
   const float scale = 1.0f / (float)g.nc;
-  for (int i = 0; i < n_fft; ++i) out[i] = (g.even ? ((i & 1) ? z[i >> 1].im : z[i >> 1].re) : z[i].re) * scale;
+  for (int i = 0; i < n_fft; ++i) {
+    const cf zz = z[gen_pad(g.even ? i >> 1 : i)];
+    out[i] = ((g.even && (i & 1)) ? zz.im : zz.re) * scale;
+  }
   return 0;
 }
 
