@@ -118,6 +118,7 @@ struct rfx_plan {
   GenGeom gg{};
   GenTables gt{};
   void* d_gen_tables = nullptr;
+  int* d_gen_rev = nullptr;
   int frame_stride = kFrameStride;
 };
 
@@ -248,6 +249,11 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
     pl->gt.lo2 = d + kGenTwLo + gg.nhi;
     pl->gt.hi2 = d + 2 * kGenTwLo + gg.nhi;
     pl->gt.win = pl->d_win;
+    std::vector<int> rev(gg.nc);
+    for (int k = 0; k < gg.nc; ++k) rev[k] = gen_digit_reverse(gg, k);
+    RFX_HIP(hipMalloc(&pl->d_gen_rev, rev.size() * sizeof(int)));
+    RFX_HIP(hipMemcpy(pl->d_gen_rev, rev.data(), rev.size() * sizeof(int), hipMemcpyHostToDevice));
+    pl->gt.rev = pl->d_gen_rev;
   }
 
   if (h_melfb) {
@@ -460,6 +466,7 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_band_lo);
     (void)hipFree(plan->d_band_addr);
     (void)hipFree(plan->d_gen_tables);
+    (void)hipFree(plan->d_gen_rev);
   }
   delete plan;
   return RFX_OK;

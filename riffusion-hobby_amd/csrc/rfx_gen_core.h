@@ -68,20 +68,9 @@ RFX_HD int gen_div(int j, int Ns, float inv_ns) {
   return q;
 }
 
+// the R-point DFT of v into y (INV: exp(+i ...) kernels); root = exp(-2 pi i t / R), used by the O(R^2) radices only
 template <int R, bool INV>
-RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, float inv_ns, int tstep, const cf* lo, const cf* hi,
-                          const cf (&root)[R]) {
-  const int jd = gen_div(j, Ns, inv_ns);
-  const int k = j - jd * Ns;
-  cf v[R];
-  v[0] = in[gen_pad(j)];
-#pragma unroll
-  for (int q = 1; q < R; ++q) {
-    const cf w = gen_tw(lo, hi, q * k * tstep);  // q * k * tstep < nc
-    const cf x = in[gen_pad(j + q * m)];
-    v[q] = INV ? cmulc(x, w) : cmul(x, w);
-  }
-  cf y[R];
+RFX_HD void gen_dft(const cf (&v)[R], cf (&y)[R], const cf (&root)[R]) {
   if (R == 2) {
     y[0] = cf{v[0].re + v[1].re, v[0].im + v[1].im};
     y[1] = cf{v[0].re - v[1].re, v[0].im - v[1].im};
@@ -135,9 +124,77 @@ RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, float inv
       y[p] = acc;
     }
   }
+}
+
+template <int R, bool INV>
+RFX_HD void gen_butterfly(const cf* in, cf* out, int j, int m, int Ns, float inv_ns, int tstep, const cf* lo, const cf* hi,
+                          const cf (&root)[R]) {
+  const int jd = gen_div(j, Ns, inv_ns);
+  const int k = j - jd * Ns;
+  cf v[R];
+  v[0] = in[gen_pad(j)];
+#pragma unroll
+  for (int q = 1; q < R; ++q) {
+    const cf w = gen_tw(lo, hi, q * k * tstep);  // q * k * tstep < nc
+    const cf x = in[gen_pad(j + q * m)];
+    v[q] = INV ? cmulc(x, w) : cmul(x, w);
+  }
+  cf y[R];
+  gen_dft<R, INV>(v, y, root);
   const int j0 = jd * Ns * R + k;
 #pragma unroll
   for (int p = 0; p < R; ++p) out[gen_pad(j0 + p * Ns)] = y[p];
+}
+
+// ---- in-place alternative (half the LDS: two workgroups per CU at 48 kHz).  Forward = decimation in frequency: pass s
+// splits blocks of length L into R sub-blocks of length m = L / R (butterfly, then twiddle W_L^{i p}); the spectrum comes
+// out digit-reversed (bin k at rev[k]).  Inverse = decimation in time over the same (L, m) pairs in reverse order (conjugate
+// twiddle, then butterfly) on digit-reversed input, natural order out.
+template <int R, bool INV>
+RFX_HD void gen_ip_butterfly(cf* buf, int j, int m, float inv_m, int L, int tstep, const cf* lo, const cf* hi, const cf (&root)[R]) {
+  const int blk = gen_div(j, m, inv_m);
+  const int i = j - blk * m;
+  const int base = blk * L + i;
+  cf v[R], y[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const cf x = buf[base + q * m];
+    v[q] = (INV && q > 0) ? cmulc(x, gen_tw(lo, hi, q * i * tstep)) : x;  // q * i * tstep < nc
+  }
+  gen_dft<R, INV>(v, y, root);
+#pragma unroll
+  for (int p = 0; p < R; ++p) buf[base + p * m] = (!INV && p > 0) ? cmul(y[p], gen_tw(lo, hi, p * i * tstep)) : y[p];
+}
+template <int R, bool INV>
+RFX_HD void gen_ip_stage_r(cf* buf, int nc, int L, const cf* lo, const cf* hi, int tid, int nthr) {
+  const int m = L / R, tstep = nc / L, nbf = nc / R;
+  const float inv_m = 1.0f / (float)m;
+  cf root[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) root[t] = gen_tw(lo, hi, t * (nc / R));
+  for (int j = tid; j < nbf; j += nthr) gen_ip_butterfly<R, INV>(buf, j, m, inv_m, L, tstep, lo, hi, root);
+}
+template <bool INV, int MAXR = 13>
+RFX_HD void gen_ip_stage(cf* buf, int nc, int L, int R, const cf* lo, const cf* hi, int tid, int nthr) {
+  switch (R) {
+    case 2: gen_ip_stage_r<2, INV>(buf, nc, L, lo, hi, tid, nthr); break;
+    case 3: gen_ip_stage_r<3, INV>(buf, nc, L, lo, hi, tid, nthr); break;
+    case 4: gen_ip_stage_r<4, INV>(buf, nc, L, lo, hi, tid, nthr); break;
+    case 5: gen_ip_stage_r<5, INV>(buf, nc, L, lo, hi, tid, nthr); break;
+    case 7: if (MAXR >= 7) gen_ip_stage_r<7, INV>(buf, nc, L, lo, hi, tid, nthr); break;
+    case 11: if (MAXR >= 11) gen_ip_stage_r<11, INV>(buf, nc, L, lo, hi, tid, nthr); break;
+    default: if (MAXR >= 13) gen_ip_stage_r<13, INV>(buf, nc, L, lo, hi, tid, nthr); break;
+  }
+}
+// position of bin k after the forward in-place passes (and where the inverse expects it)
+RFX_HD int gen_digit_reverse(const GenGeom& g, int k) {
+  int pos = 0, len = g.nc;
+  for (int s = 0; s < g.nstages; ++s) {
+    len /= g.radix[s];
+    pos += (k % g.radix[s]) * len;
+    k /= g.radix[s];
+  }
+  return pos;
 }
 
 template <int R, bool INV>
@@ -174,9 +231,11 @@ RFX_HD int gen_radix_class(const int* radix, int nstages) {
 
 // ---- real <-> packed-complex split.  Z: the nc-point complex spectrum (LDS), lo2/hi2: two-level table of
 // exp(-2 pi i k / n_fft).  Returns bin k (0 <= k <= n_fft/2) of the real FFT.
-RFX_HD cf gen_split_forward(const GenGeom& g, const cf* Z, const cf* lo2, const cf* hi2, int k) {
-  if (!g.even) return Z[gen_pad(k)];
-  const cf zk = Z[gen_pad(k == g.nc ? 0 : k)], zc = Z[gen_pad(k == 0 ? 0 : g.nc - k)];
+// `rev` (nullable): position of element k inside Z (digit-reversed after the in-place passes)
+RFX_HD cf gen_split_forward(const GenGeom& g, const cf* Z, const cf* lo2, const cf* hi2, int k, const int* rev = nullptr) {
+  auto at = [&](int i) { return Z[rev ? rev[i] : gen_pad(i)]; };
+  if (!g.even) return at(k);
+  const cf zk = at(k == g.nc ? 0 : k), zc = at(k == 0 ? 0 : g.nc - k);
   const cf s{zk.re + zc.re, zk.im - zc.im}, d{zk.re - zc.re, zk.im + zc.im};  // Z[k] +- conj Z[nc-k]
   const cf p = cmul(gen_tw(lo2, hi2, k), d);
   return cf{0.5f * (s.re + p.im), 0.5f * (s.im - p.re)};  // (s - i p) / 2

@@ -3,14 +3,14 @@
 //
 // The 44.1 kHz geometry of the reference's defaults runs on the specialised engine (rfx_core.h: hard-wired 40 x 21 x 21
 // factorisation, one fused launch per Griffin-Lim iteration).  Every other sample rate / window / padding the reference
-// accepts (cli.py:43 takes the rate from the input file; spectrogram_params.py:62-81) runs here: a Stockham FFT over a
-// runtime radix list with both buffers in LDS (rfx_gen_core.h), one workgroup per frame, and Griffin-Lim executed in
+// accepts (cli.py:43 takes the rate from the input file; spectrogram_params.py:62-81) runs here: an in-place FFT over a
+// runtime radix list in LDS (rfx_gen_core.h), one workgroup per frame, and Griffin-Lim executed in
 // the reference's own op order with its spectral state in HBM:
 //     x_k     = ISTFT(Z_k)                 gen_istft_kernel (frames) + gen_fold_kernel (overlap-add / envelope)
 //     rebuilt = STFT(x_k)                  gen_stft_kernel<GL>, whose epilogue does the per-bin update
 //     Z_{k+1} = S * normalise(rebuilt - m * tprev),  tprev <- rebuilt
 // 36 B per bin and iteration (|S| 4 + tprev 8 + 8 + Z 8 + 8) plus the windowed frames.  Slower than the specialised
-// path by design (measured: 3-6x per tile), bit-reproducible (no atomics), same entry points.
+// path by design (measured: 2.6-5.7x per tile), bit-reproducible (no atomics), same entry points.
 #include <hip/hip_runtime.h>
 
 #include "rfx_gen_core.h"
@@ -18,7 +18,15 @@
 
 namespace rfx {
 
-constexpr int kGenThreads = 1024;  // 16 waves: the LDS footprint allows one workgroup per CU at 48 kHz, so it has to fill the CU alone
+// RFX_GEN_INPLACE=1: in-place passes (rfx_gen_core.h) in ONE LDS buffer, so two 512-thread workgroups share a CU at 48 kHz
+// and cover each other's barrier / LDS waits; 0: Stockham autosort between two buffers, one 1024-thread workgroup per CU.
+#ifndef RFX_GEN_INPLACE
+#define RFX_GEN_INPLACE 1
+#endif
+#ifndef RFX_GEN_THREADS
+#define RFX_GEN_THREADS (RFX_GEN_INPLACE ? 512 : 1024)
+#endif
+constexpr int kGenThreads = RFX_GEN_THREADS;
 
 struct GenLds {
   cf* a;
@@ -32,7 +40,7 @@ struct GenLds {
 __device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const GenTables& tb) {
   GenLds l;
   l.a = reinterpret_cast<cf*>(smem);
-  l.b = l.a + gen_buf_elems(g.nc);
+  l.b = l.a + (RFX_GEN_INPLACE ? 0 : gen_buf_elems(g.nc));
   l.lo = l.b + gen_buf_elems(g.nc);
   l.hi = l.lo + kGenTwLo;
   l.lo2 = l.hi + g.nhi;
@@ -46,11 +54,25 @@ __device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const Ge
   return l;
 }
 
-size_t gen_lds_bytes(const GenGeom& g) { return sizeof(cf) * (2 * (size_t)gen_buf_elems(g.nc) + 2 * kGenTwLo + g.nhi + g.nhi2); }
+size_t gen_lds_bytes(const GenGeom& g) {
+  return sizeof(cf) * ((RFX_GEN_INPLACE ? 1 : 2) * (size_t)gen_buf_elems(g.nc) + 2 * kGenTwLo + g.nhi + g.nhi2);
+}
 
 // all passes of the nc-point FFT; data starts in l.a, the result's buffer is returned.  Barriers inside.
 template <bool INV, int MAXR>
 __device__ __forceinline__ cf* gen_fft(const GenGeom& g, const GenLds& l) {
+#if RFX_GEN_INPLACE
+  int L = INV ? 1 : g.nc;  // forward: blocks shrink from nc; inverse: they grow from the last radix
+  for (int i = 0; i < g.nstages; ++i) {
+    const int R = g.radix[INV ? g.nstages - 1 - i : i];
+    if (INV) L *= R;
+    __syncthreads();
+    gen_ip_stage<INV, MAXR>(l.a, g.nc, L, R, l.lo, l.hi, (int)threadIdx.x, (int)blockDim.x);
+    if (!INV) L /= R;
+  }
+  __syncthreads();
+  return l.a;
+#endif
   cf* in = l.a;
   cf* out = l.b;
   int Ns = 1;
@@ -103,7 +125,7 @@ __global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
         if (MODE == kGenGl) { a.tprev[base + k] = cf{0.f, 0.f}; a.z[base + k] = cf{0.f, 0.f}; }
         continue;
       }
-      const cf X = gen_split_forward(g, Z, l.lo2, l.hi2, k);
+      const cf X = gen_split_forward(g, Z, l.lo2, l.hi2, k, RFX_GEN_INPLACE ? a.tb.rev : nullptr);
       if (MODE == kGenMag) a.mag[base + k] = sqrtf(fmaf(X.re, X.re, X.im * X.im));
       if (MODE == kGenSpec) a.spec[base + k] = X;
       if (MODE == kGenGl) {
@@ -134,7 +156,8 @@ __global__ void __launch_bounds__(kGenThreads) gen_istft_kernel(GenIstftArgs a) 
       return cf{s * ang.re, s * ang.im};
     };
     __syncthreads();
-    for (int k = threadIdx.x; k < g.nc; k += blockDim.x) l.a[gen_pad(k)] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
+    for (int k = threadIdx.x; k < g.nc; k += blockDim.x)
+      l.a[RFX_GEN_INPLACE ? a.tb.rev[k] : gen_pad(k)] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
     const cf* z = gen_fft<true, MAXR>(g, l);
     float* __restrict__ out = a.frames + (size_t)fr * g.win;
     for (int j = threadIdx.x; j < g.win; j += blockDim.x) {
@@ -222,7 +245,8 @@ static int gen_grid(const GenGeom& g, int num_cus, long long nframes) {
   const size_t lds = gen_lds_bytes(g);
   int per_cu = (int)((160u * 1024u) / (lds + 512));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 2) per_cu = 2;  // 1024 threads each: two workgroups fill the CU's 32 wave slots
+  const int by_waves = 2048 / kGenThreads;  // 32 wave slots per CU
+  if (per_cu > by_waves) per_cu = by_waves;
   long long n = (long long)num_cus * per_cu;
   return (int)(n < nframes ? n : nframes);
 }

@@ -128,6 +128,7 @@ struct GenTables {
   const cf* lo2;     // [128]   exp(-2 pi i t / n_fft)
   const cf* hi2;     // [nhi2]  exp(-2 pi i 128 t / n_fft)
   const float* win;  // [win]
+  const int* rev;    // [nc] position of element k after the in-place forward passes (digit reversal)
 };
 struct GenStftArgs {
   GenGeom g;

@@ -43,9 +43,51 @@ cf* run_fft(const GenGeom& g, const Tables& t, cf* a, cf* b, int nthr) {
   }
   return in;
 }
+// in-place passes: forward DIF over blocks L = nc, nc/R0, ...; inverse DIT over the same (L, m) pairs in reverse order
+template <bool INV>
+void run_fft_inplace(const GenGeom& g, const Tables& t, cf* buf, int nthr) {
+  int Ls[kGenMaxStages];
+  int L = g.nc;
+  for (int s = 0; s < g.nstages; ++s) { Ls[s] = L; L /= g.radix[s]; }
+  for (int i = 0; i < g.nstages; ++i) {
+    const int s = INV ? g.nstages - 1 - i : i;
+    for (int tid = 0; tid < nthr; ++tid) gen_ip_stage<INV>(buf, g.nc, Ls[s], g.radix[s], t.lo.data(), t.hi.data(), tid, nthr);
+  }
+}
 }  // namespace
 
 extern "C" {
+
+int emu_gen_rfft_inplace(int n_fft, const float* frame, float* out, int nthr) {
+  GenGeom g; Tables t;
+  if (!make_geom(n_fft, n_fft, 1, g, t)) return -1;
+  std::vector<cf> a(g.nc);
+  std::vector<int> rev(g.nc);
+  for (int k = 0; k < g.nc; ++k) rev[k] = gen_digit_reverse(g, k);
+  for (int n = 0; n < g.nc; ++n) a[n] = g.even ? cf{frame[2 * n], frame[2 * n + 1]} : cf{frame[n], 0.f};
+  run_fft_inplace<false>(g, t, a.data(), nthr);
+  for (int k = 0; k < g.n_stft; ++k) {
+    const cf X = gen_split_forward(g, a.data(), t.lo2.data(), t.hi2.data(), k, rev.data());
+    out[2 * k] = X.re; out[2 * k + 1] = X.im;
+  }
+  return 0;
+}
+
+int emu_gen_irfft_inplace(int n_fft, const float* spec, float* out, int nthr) {
+  GenGeom g; Tables t;
+  if (!make_geom(n_fft, n_fft, 1, g, t)) return -1;
+  std::vector<cf> a(g.nc);
+  auto X = [&](int k) { return cf{spec[2 * k], spec[2 * k + 1]}; };
+  for (int k = 0; k < g.nc; ++k) a[gen_digit_reverse(g, k)] = gen_split_inverse(g, X, t.lo2.data(), t.hi2.data(), k);
+  run_fft_inplace<true>(g, t, a.data(), nthr);
+  const float scale = 1.0f / (float)g.nc;
+  for (int i = 0; i < n_fft; ++i) {
+    const cf zz = a[g.even ? i >> 1 : i];
+    out[i] = ((g.even && (i & 1)) ? zz.im : zz.re) * scale;
+  }
+  return 0;
+}
+
 
 // returns the number of passes (0: unsupported length); radices written to radix_out[16]
 int emu_gen_factor(int n_fft, int* radix_out) {

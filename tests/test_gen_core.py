@@ -55,6 +55,22 @@ def test_real_fft_and_inverse_match_numpy(emu, n_fft):
     assert np.array_equal(out, out2)
 
 
+@pytest.mark.parametrize("n_fft", LENGTHS)
+def test_inplace_passes_match_numpy(emu, n_fft):
+    """The in-place variant (forward decimation in frequency -> digit-reversed spectrum, inverse decimation in time)."""
+    rng = np.random.default_rng(n_fft + 1)
+    x = rng.standard_normal(n_fft).astype(np.float32)
+    out = np.zeros(2 * (n_fft // 2 + 1), np.float32)
+    assert emu.emu_gen_rfft_inplace(n_fft, x.ctypes.data_as(FP), out.ctypes.data_as(FP), 96) == 0
+    ref = np.fft.rfft(x.astype(np.float64))
+    assert np.abs(out.view(np.complex64) - ref).max() / np.abs(ref).max() < 3e-6
+    X = (rng.standard_normal(n_fft // 2 + 1) + 1j * rng.standard_normal(n_fft // 2 + 1)).astype(np.complex64)
+    back = np.zeros(n_fft, np.float32)
+    assert emu.emu_gen_irfft_inplace(n_fft, X.view(np.float32).ctypes.data_as(FP), back.ctypes.data_as(FP), 50) == 0
+    want = np.fft.irfft(X.astype(np.complex128), n_fft)
+    assert np.abs(back - want).max() / np.abs(want).max() < 3e-6
+
+
 def test_factorisation_and_unsupported_lengths(emu):
     radix = np.zeros(16, np.int32)
     n = emu.emu_gen_factor(19200, radix.ctypes.data_as(IP))
