@@ -149,3 +149,45 @@ def test_cli_round_trips_like_the_reference_tests(golden_dir, tmp_path):
         Image.open(os.path.join(golden_dir, "og_beat_64.png")).save(str(tiles / f"t{i}.png"))
     cli.main(["images-to-audio-batch", "--image-dir", str(tiles), "--output-dir", str(tmp_path / "wavs")])
     assert sorted(os.listdir(tmp_path / "wavs")) == ["t0.wav", "t1.wav", "t2.wav"]
+
+
+def test_cli_other_sample_rates_and_batch_flags(golden_dir, tmp_path):
+    """The reference takes the sample rate from the input file (cli.py:43): a 48 kHz clip goes through the generic engine, and
+    `audio-to-images-batch` resamples mixed-rate files to --sample-rate, skips what it cannot read and defaults to stereo jpg
+    (cli.py:134-204)."""
+    import os
+
+    from PIL import Image
+
+    from riffusion import cli
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import audio_util
+
+    src = audio_util.PcmSegment.from_wav(os.path.join(golden_dir, "clip_2_start_103694_ms_duration_5678_ms.wav"))
+    wav48 = str(tmp_path / "clip48.wav")
+    src.set_frame_rate(48000).export(wav48, format="wav")
+    png48 = str(tmp_path / "clip48.png")
+    cli.main(["audio-to-image", "--audio", wav48, "--image", png48])
+    im = Image.open(png48)
+    p = SpectrogramParams.from_exif(im.getexif())
+    assert p.sample_rate == 48000 and p.n_fft == 19200 and im.size[1] == 512 and im.size[0] == 1 + int(48000 * 250400 / 44100) // 480
+    back = str(tmp_path / "back48.wav")
+    cli.main(["image-to-audio", "--image", png48, "--audio", back])
+    seg = audio_util.PcmSegment.from_wav(back)
+    assert seg.frame_rate == 48000 and seg.channels == 1 and abs(seg.duration_seconds - 5.678) < 0.02
+
+    clips = tmp_path / "clips"
+    clips.mkdir()
+    src.export(str(clips / "a.wav"), format="wav")
+    src.set_frame_rate(22050).set_channels(1).export(str(clips / "b.wav"), format="wav")
+    (clips / "broken.wav").write_bytes(b"not a wav file")
+    out = tmp_path / "images"
+    cli.main(["audio-to-images-batch", "--audio-dir", str(clips), "--output-dir", str(out)])
+    assert sorted(os.listdir(out)) == ["a.jpg", "b.jpg"]  # the unreadable file is skipped, like the reference does
+    for name in ("a.jpg", "b.jpg"):
+        with Image.open(str(out / name)) as im:
+            q = SpectrogramParams.from_exif(im.getexif())
+            assert q.stereo is True and q.sample_rate == 44100 and im.size[1] == 512 and abs(im.size[0] - 568) <= 1
+    cli.main(["audio-to-images-batch", "--audio-dir", str(clips), "--output-dir", str(tmp_path / "mono"), "--mono",
+              "--image-extension", "png", "--limit", "1"])
+    assert os.listdir(tmp_path / "mono") == ["a.png"]
