@@ -302,3 +302,28 @@ def test_inverse_mel_other_parameter_sets_use_fallback_kernels(O, kw):
     fwd = plan.mel_from_waveform(wave.cuda()).cpu()
     fref = O.mel_amplitudes_from_waveform(wave, op)
     assert torch.linalg.norm(fwd - fref) / torch.linalg.norm(fref) <= 1e-4
+
+
+@pytest.mark.parametrize("n_mels", [1024, 96])
+def test_other_filter_counts_forward_and_inverse(O, n_mels):
+    """num_frequencies other than 512 (the reference exposes it: cli.py:27, spectrogram_params.py:31): 1024 filters take the
+    unfused STFT + MFMA GEMM path forward and the general SGD kernel inverse, 96 the fused / group paths' fallbacks."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    p = SpectrogramParams(num_frequencies=n_mels, max_mel_iters=40)
+    op = O.params_from(p)
+    plan = _hip.get_plan(p, "cuda")
+    wave = synthetic_wave(2, 441 * 40 + 7, seed=n_mels)
+    ref = O.mel_amplitudes_from_waveform(wave, op)
+    got = plan.mel_from_waveform(wave.cuda()).cpu()
+    assert got.shape == ref.shape == (2, n_mels, 41)
+    assert torch.linalg.norm(got - ref) / torch.linalg.norm(ref) <= 1e-4
+    g = torch.Generator().manual_seed(1)
+    spec0 = torch.rand(2, 41, op.n_stft, generator=g)
+    want = O.inverse_mel_scale_sgd(ref, op, spec0=spec0)
+    lin = plan.unpack_magnitudes(plan.inverse_mel(ref.cuda(), 2, spec0=spec0.cuda()), 2, 41).cpu()
+    act = O.mel_filterbank(op).abs().sum(1) > 0
+    rel = float(torch.linalg.norm(lin[:, act] - want[:, act]) / torch.linalg.norm(want[:, act]))
+    print(f"n_mels {n_mels}: forward ok, InverseMelScale rel-L2 {rel:.2e}")
+    assert rel <= 1e-3 and torch.equal(lin[:, ~act], want[:, ~act])
