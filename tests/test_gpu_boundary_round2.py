@@ -166,3 +166,31 @@ def test_projection_edge_cases_zero_and_tiny_spectra(O, params):
         s = snr_db(want, got)
         print(f"scale {scale:g}: {s:.1f} dB after 4 iterations")
         assert bool(torch.isfinite(got).all()) and s >= 95.0
+
+
+def test_round_trip_like_the_reference_spectrogram_converter_test(O, golden_dir):
+    """reference test/spectrogram_converter_test.py:23-84: audio -> spectrogram -> audio without the image step, on its own
+    clip and its own parameter set (20 Hz .. 20 kHz), checking what it checks (channels, frame rate, sample width) plus the
+    duration and that the reconstruction's mel spectrogram stays close to the input's."""
+    from riffusion.spectrogram_converter import SpectrogramConverter
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import audio_util
+
+    original = audio_util.PcmSegment.from_wav(os.path.join(golden_dir, "clip_2_start_103694_ms_duration_5678_ms.wav")).set_channels(1)
+    params = SpectrogramParams(sample_rate=original.frame_rate, stereo=False, step_size_ms=10, min_frequency=20, max_frequency=20000,
+                               num_frequencies=512)
+    conv = SpectrogramConverter(params=params, device="cuda")
+    spectrogram = conv.spectrogram_from_audio(original)
+    torch.manual_seed(0)
+    result = conv.audio_from_spectrogram(spectrogram, apply_filters=True)
+    assert result.channels == original.channels == 1
+    assert result.frame_rate == original.frame_rate and result.sample_width == original.sample_width
+    assert abs(result.duration_seconds - original.duration_seconds) <= 0.011  # truncated to whole hops (10 ms)
+    # reconstruction quality: mel spectrogram of the output vs the input's, gain removed (apply_filters rescales)
+    back = conv.spectrogram_from_audio(result)
+    n = min(back.shape[-1], spectrogram.shape[-1])
+    a, b = spectrogram[..., :n].ravel().astype(np.float64), back[..., :n].ravel().astype(np.float64)
+    gain = float(a @ b / (b @ b))
+    rel = float(np.linalg.norm(a - gain * b) / np.linalg.norm(a))
+    print(f"round trip 20 Hz .. 20 kHz: mel spectrogram of the reconstruction within {rel:.3f} (relative L2) of the input's")
+    assert rel < 0.35
