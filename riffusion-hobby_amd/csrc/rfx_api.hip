@@ -114,6 +114,7 @@ struct rfx_plan {
   int band_rows = 0, Mpad = 0;
   bool fwd_unfused = false;        // debugging override (RFX_FWD_UNFUSED), read once at creation
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
+  bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
   bool generic = false;
   GenGeom gg{};
   GenTables gt{};
@@ -205,6 +206,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
   if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
   pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : 0;
+  if (const char* e = getenv("RFX_GL_LATENCY_MODE")) pl->gl_latency_mode = atoi(e) != 0;
 #ifdef RFX_TIMING
   if (const char* e = getenv("RFX_TIMING_PTR")) pl->timing = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
@@ -537,7 +539,13 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
 
 // Griffin-Lim workspace: three generations (x_{k-1}, x_k, x_{k+1}) of the two parity audio buffers, and the
 // istft normalisation table.  No spectral state is kept between iterations (see rfx_gl.hip).
-static void gl_layout(int B, int T, size_t& off_audio, size_t& off_scale, size_t& total, int& Lpad) {
+// Small batches take the per-frame kernels (rfx_gl.hip: gl_frame_kernel + gl_fold_kernel): at most four frames per resident
+// workgroup slot, where the run-based kernel (>= 10 frames per workgroup) would leave most of the chip idle.
+static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
+  return plan->gl_latency_mode && (long long)B * T <= 4LL * plan->num_cus * plan->gl_wgs_per_cu;
+}
+
+static void gl_layout(const rfx_plan* plan, int B, int T, size_t& off_audio, size_t& off_scale, size_t& off_frames, size_t& total, int& Lpad) {
   const int L = kHop * (T - 1);
   Lpad = (int)align_up((size_t)L, 64);
   size_t o = 0;
@@ -545,6 +553,8 @@ static void gl_layout(int B, int T, size_t& off_audio, size_t& off_scale, size_t
   o += align_up(6 * (size_t)B * Lpad * sizeof(float), 256);
   off_scale = o;
   o += align_up((size_t)Lpad * sizeof(float), 256);
+  off_frames = o;
+  if (gl_use_latency_mode(plan, B, T)) o += align_up(gl_frame_buffer_bytes(B, T), 256);
   total = o;
 }
 
@@ -638,9 +648,9 @@ size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
     gen_gl_layout(plan, B, T, a, b, c, d, total, Lpad);
     return total;
   }
-  size_t a, c, total;
+  size_t a, c, fr, total;
   int Lpad;
-  gl_layout(B, T, a, c, total, Lpad);
+  gl_layout(plan, B, T, a, c, fr, total, Lpad);
   return total;
 }
 
@@ -662,9 +672,9 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
                                  "(reflect padding 8820 needs more than 8820 samples, i.e. at least 22 frames)");
   RFX_ON_DEVICE(plan->device);
   hipStream_t stream = (hipStream_t)stream_;
-  size_t off_audio, off_scale, total;
+  size_t off_audio, off_scale, off_frames, total;
   int Lpad;
-  gl_layout(B, T, off_audio, off_scale, total, Lpad);
+  gl_layout(plan, B, T, off_audio, off_scale, off_frames, total, Lpad);
   if (workspace_bytes < total) return fail(RFX_ERR_WORKSPACE, "rfx_griffinlim: workspace too small");
   const int L = kHop * (T - 1);
   char* ws = (char*)d_workspace;
@@ -676,6 +686,44 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
 
   hipLaunchKernelGGL(out_scale_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, plan->d_win, scale, T, L);
   RFX_HIP(hipGetLastError());
+
+  if (gl_use_latency_mode(plan, B, T)) {
+    // x_k lives in generation k % 3 (one folded buffer each: gen[k][0]); frame kernel + fold per iteration
+    GlFrameArgs fa;
+    fa.S = d_mag_slots;
+    fa.angles0 = (const cf*)d_angles0_slots;
+    fa.frames = (float*)(ws + off_frames);
+    fa.tw1 = plan->d_tw1;
+    fa.tw2 = plan->d_tw2;
+    fa.win = plan->d_win;
+    fa.B = B;
+    fa.T = T;
+    fa.L = L;
+    fa.Lpad = Lpad;
+    fa.mom = momentum / (1.f + momentum);
+    fa.seed = seed;
+    const long long nframes = (long long)B * T;
+    const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu;
+    const int nblocks = (int)(nframes < slots ? nframes : slots);
+    EventList events;
+    if (h_launch_ms) {
+      RFX_HIP(events.create(n_iter + 2));
+      RFX_HIP(hipEventRecord(events.ev[0], stream));
+    }
+    for (int it = 0; it <= n_iter; ++it) {
+      fa.audio_in = gen[(it + 2) % 3][0];    // x_{it-1}
+      fa.audio_prev = gen[(it + 1) % 3][0];  // x_{it-2}
+      RFX_HIP(launch_gl_frame(it == 0 ? 0 : it == 1 ? 1 : 2, fa, nblocks, stream));
+      const bool last = it == n_iter;
+      RFX_HIP(launch_gl_fold(fa.frames, scale, last ? d_wave_out : gen[it % 3][0], B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+      if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
+    }
+    if (h_launch_ms) {
+      RFX_HIP(hipEventSynchronize(events.ev[n_iter + 1]));
+      for (int i = 0; i <= n_iter; ++i) RFX_HIP(hipEventElapsedTime(&h_launch_ms[i], events.ev[i], events.ev[i + 1]));
+    }
+    return RFX_OK;
+  }
 
   GlArgs g;
   g.S = d_mag_slots;

@@ -276,6 +276,121 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   for (int j = 0; j < 9; ++j) emit(t1 - 4 + j, acc[j]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small batches (a server decodes ONE tile per request, reference server.py:152-164): the run-based kernel above needs
+// >= 10 consecutive frames per workgroup, i.e. at most T/10 = 51 workgroups per clip-channel - a fifth of the chip for a
+// mono tile.  Here every frame is its own unit of work: a workgroup analyses frame t of x_k - m x_{k-1}, projects, and
+// writes the frame's 4410 windowed synthesis samples to a frame buffer; gl_fold_kernel then overlap-adds the (up to) ten
+// frames that cover a sample and applies torch.istft's envelope division.  Twice the launches and 35 KB of extra traffic
+// per frame, but 512 workgroups per clip-channel: one iteration of a single tile takes ~25 us instead of ~90 us.
+// Chosen by the host for B*T <= 4 frames per resident workgroup slot (RFX_GL_LATENCY_MODE=0 disables).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kFramePitch = 4416;  // 4410 samples per synthesis frame, rounded up to whole 64-byte lines
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_frame_kernel(GlFrameArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ThreadId t = thread_id();
+  const FrameCtx f = frame_ctx(smem, t, g.tw1, g.tw2);
+  const rsrc_t win = make_rsrc(g.win, kWin * 4);
+  const unsigned npr4 = (unsigned)t.npr * 4u;
+  const unsigned q16 = (unsigned)slot_qp(t.npr) * 16u;
+  float wv[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) wv[j] = ld1(win, npr4, (unsigned)j * (kHop * 4u));
+  Tw1 tw1;
+  if (MODE != 0) load_tw1(tw1, f);
+  __syncthreads();  // tw2 table in LDS
+
+  const long long nframes = (long long)g.B * g.T;
+  for (long long gf = blockIdx.x; gf < nframes; gf += gridDim.x) {
+    const int clip = (int)(gf / g.T), fr = (int)(gf - (long long)clip * g.T);
+    const size_t clip_slots = (size_t)g.T * kFrameStride;
+    const rsrc_t Ssrc = make_rsrc(g.S + clip * clip_slots, clip_slots * sizeof(float));
+    const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
+    cf R[21];
+    MagRegs mag;
+    if (MODE != 0) {
+      const rsrc_t in = make_rsrc(g.audio_in + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+      const rsrc_t pv = make_rsrc(g.audio_prev + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+      float u[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const unsigned p4 = (unsigned)reflect_index((fr + j - kHalfHops) * kHop + t.npr, g.L) * 4u;
+        float x = ld1(in, p4, 0);
+        if (MODE == 2) x = fmaf(-g.mom, ld1(pv, p4, 0), x);
+        u[j] = x * wv[j];
+      }
+      frame_forward_tw(u, R, f, t, tw1, [&] { mag_issue(mag, Ssrc, foff, q16); });
+#pragma unroll
+      for (int kb = 0; kb < 21; ++kb) R[kb] = gl_project(R[kb], mag_at(mag, kb));
+    } else {
+      mag_issue(mag, Ssrc, foff, q16);
+      if (g.angles0) {
+        const rsrc_t init = make_rsrc(g.angles0 + clip * clip_slots, clip_slots * sizeof(cf));
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          const v4f v = ld4<RFX_STREAM_AUX>(init, q16, 2u * foff + (unsigned)i * (kQPad * 16u));
+          R[2 * i] = cf{v.x, v.y};
+          R[2 * i + 1] = cf{v.z, v.w};
+        }
+        const v2f w = ld2<RFX_STREAM_AUX>(init, q16 >> 1, 2u * foff + 20u * kQPad * 8u);
+        R[20] = cf{w.x, w.y};
+      } else {
+        const unsigned long long rng_base = ((unsigned long long)clip * g.T + fr) * kBins;  // same stream as gl_iter_kernel
+#pragma unroll
+        for (int kb = 0; kb < 21; ++kb) {
+          bool cj;
+          const int bin = slot_bin(t.k1, t.idx, kb, &cj);
+          const cf r = rand_unit_pair(g.seed, rng_base + bin);
+          R[kb] = cf{r.re, cj ? -r.im : r.im};
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 21; ++kb) {
+        const float s = mag_at(mag, kb);
+        R[kb] = cf{s * R[kb].re, s * R[kb].im};
+      }
+    }
+    float y[10];
+    frame_inverse_tw(R, y, f, t, tw1);
+    if (t.active) {
+      float* __restrict__ out = g.frames + (size_t)gf * kFramePitch + t.npr;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) out[j * kHop] = y[j] * wv[j];
+    }
+    __syncthreads();  // the next frame's first LDS stores overwrite rows other waves are still gathering in P1'
+  }
+}
+
+// x[clip][p] = out_scale[p] * sum over the frames t = blk-4 .. blk+5 that cover hop block blk = p / 441 (fixed order)
+__global__ void __launch_bounds__(256) gl_fold_kernel(const float* __restrict__ frames, const float* __restrict__ scale,
+                                                      float* __restrict__ out, int T, int L, size_t out_stride) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int clip = blockIdx.y;
+  if (p >= L) return;
+  const int blk = p / kHop, n = p - blk * kHop;
+  const int tlo = max(blk - 4, 0), thi = min(blk + 5, T - 1);
+  float acc = 0.f;
+  for (int t = tlo; t <= thi; ++t) acc += frames[((size_t)clip * T + t) * kFramePitch + (blk - t + kHalfHops) * kHop + n];
+  out[(size_t)clip * out_stride + p] = acc * scale[p];
+}
+
+hipError_t launch_gl_frame(int mode, const GlFrameArgs& g, int nblocks, hipStream_t stream) {
+  const size_t lds = kFrameDynLdsBytes;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(gl_frame_kernel<0>, dim3(nblocks), dim3(kThreads), lds, stream, g); break;
+    case 1: hipLaunchKernelGGL(gl_frame_kernel<1>, dim3(nblocks), dim3(kThreads), lds, stream, g); break;
+    default: hipLaunchKernelGGL(gl_frame_kernel<2>, dim3(nblocks), dim3(kThreads), lds, stream, g); break;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_gl_fold(const float* frames, const float* scale, float* out, int B, int T, int L, size_t out_stride, hipStream_t stream) {
+  hipLaunchKernelGGL(gl_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, scale, out, T, L, out_stride);
+  return hipGetLastError();
+}
+size_t gl_frame_buffer_bytes(int B, int T) { return (size_t)B * T * kFramePitch * sizeof(float); }
+
 // wave[b][p] = A0 + A1 : fold the two parity buffers into the caller's (B, L) tensor
 __global__ void gl_combine_kernel(const float* a0, const float* a1, float* out, int L, int Lpad, size_t total) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,7 +417,10 @@ hipError_t prepare_gl_kernels() {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void*)gl_iter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)gl_iter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes)) != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)gl_iter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+  if ((e = hipFuncSetAttribute((const void*)gl_iter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)gl_frame_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)gl_frame_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes)) != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)gl_frame_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
 }
 
 int gl_blocks_per_cu() {

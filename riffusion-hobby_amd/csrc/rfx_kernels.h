@@ -31,6 +31,24 @@ hipError_t prepare_gl_kernels();
 int gl_blocks_per_cu();  // resident Griffin-Lim workgroups per CU on the current device (occupancy query)
 hipError_t launch_gl_combine(const float* a0, const float* a1, float* out, int B, int L, int Lpad, hipStream_t stream);
 
+// small-batch (latency) form: one frame per unit of work, synthesis frames to a buffer, then a fold
+struct GlFrameArgs {
+  const float* S;           // [B*T][kFrameStride] magnitudes
+  const cf* angles0;        // optional injected initial angles (MODE 0)
+  const float* audio_in;    // x_k      [B][Lpad]
+  const float* audio_prev;  // x_{k-1}  (MODE 2)
+  float* frames;            // [B*T][4416] windowed synthesis frames
+  const cf* tw1;
+  const cf* tw2;
+  const float* win;
+  int B, T, L, Lpad;
+  float mom;
+  unsigned long long seed;
+};
+hipError_t launch_gl_frame(int mode, const GlFrameArgs& g, int nblocks, hipStream_t stream);
+hipError_t launch_gl_fold(const float* frames, const float* scale, float* out, int B, int T, int L, size_t out_stride, hipStream_t stream);
+size_t gl_frame_buffer_bytes(int B, int T);
+
 // layout conversion between the reference's (B, n_stft, T) tensors and slot-major frames
 hipError_t launch_pack_mag(const float* lin_bft, float* S_slots, int B, int T, hipStream_t stream);
 hipError_t launch_pack_angles(const cf* ang_bft, cf* slots, int B, int T, hipStream_t stream);

@@ -68,14 +68,23 @@ def test_mono_tile_full_size_inverse_mel_and_griffinlim32(O):
 
     # ---- Griffin-Lim 32 on identical magnitudes (the oracle's), T = 512
     want = O.griffinlim(want_lin, op, angles0=angles0, n_iter=32)
-    slots = plan.pack_magnitudes(want_lin.cuda())
-    a0 = plan.pack_complex(angles0.cuda())
-    got = plan.griffinlim(slots, 1, T_FULL, 32, 0.99, angles0_slots=a0).cpu()
-    s32 = snr_db(want, got)
-    s4 = snr_db(O.griffinlim(want_lin, op, angles0=angles0, n_iter=4), plan.griffinlim(slots, 1, T_FULL, 4, 0.99, angles0_slots=a0).cpu())
-    print(f"Griffin-Lim T=512: SNR {s4:.1f} dB after 4 iterations, {s32:.1f} dB after 32")
-    assert got.shape == want.shape == (1, 441 * (T_FULL - 1))
-    assert s4 >= 95.0 and s32 >= 60.0
+    want4 = O.griffinlim(want_lin, op, angles0=angles0, n_iter=4)
+    # both device forms of Griffin-Lim: a single tile takes the small-batch kernels by default; the run-based kernel of the
+    # headline batch is forced through a plan created under RFX_GL_LATENCY_MODE=0
+    os.environ["RFX_GL_LATENCY_MODE"] = "0"
+    try:
+        plan_runs = _plan(SpectrogramParams(max_mel_iters=197))
+    finally:
+        os.environ.pop("RFX_GL_LATENCY_MODE")
+    for name, pl in (("small-batch kernels", plan), ("run-based kernel", plan_runs)):
+        slots = pl.pack_magnitudes(want_lin.cuda())
+        a0 = pl.pack_complex(angles0.cuda())
+        got = pl.griffinlim(slots, 1, T_FULL, 32, 0.99, angles0_slots=a0).cpu()
+        s32 = snr_db(want, got)
+        s4 = snr_db(want4, pl.griffinlim(slots, 1, T_FULL, 4, 0.99, angles0_slots=a0).cpu())
+        print(f"Griffin-Lim T=512, {name}: SNR {s4:.1f} dB after 4 iterations, {s32:.1f} dB after 32")
+        assert got.shape == want.shape == (1, 441 * (T_FULL - 1))
+        assert s4 >= 95.0 and s32 >= 60.0
 
     # ---- the whole member function, both initial values injected (device magnitudes feed the device Griffin-Lim)
     from riffusion.spectrogram_converter import SpectrogramConverter

@@ -1,29 +1,20 @@
-"""Latency probe: one 512x512 tile (and small batches) through the full uint8 -> int16 path."""
-import json, os, sys, time
+"""Single-request latency: one call of SpectrogramImageConverter.audio_from_spectrogram_images for 1 / 2 / 4 / 8 / 16 tiles."""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "riffusion-hobby_amd"))
 import numpy as np, torch
-from riffusion import _hip
+from riffusion.spectrogram_image_converter import SpectrogramImageConverter
 from riffusion.spectrogram_params import SpectrogramParams
-from riffusion.util import image_util
 
-out = {}
 for stereo in (False, True):
-    p = SpectrogramParams(stereo=stereo)
-    plan = _hip.get_plan(p, "cuda")
-    C = 2 if stereo else 1
-    lut = torch.from_numpy(image_util.decode_lut(0.25, 30e6)).cuda()
-    for B in (1, 2, 4, 8, 16, 32):
-        tiles = torch.from_numpy(np.random.default_rng(B).integers(0, 256, size=(B, 512, 512, 3), dtype=np.uint8)).cuda()
-        def step(seed):
-            mel = plan.image_decode(tiles, stereo, lut)
-            lin = plan.inverse_mel(mel, C, seed=seed)
-            wave = plan.griffinlim(lin, B * C, 512, 32, 0.99, seed=seed + 1)
-            return plan.pcm16(wave, channels=C, normalize=True)[0]
-        for i in range(2): step(i)
-        torch.cuda.synchronize(); t = time.perf_counter()
-        K = 5
-        for i in range(K): step(10 + i)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / K
-        out[f"{'stereo' if stereo else 'mono'}_B{B}"] = {"ms": round(dt * 1e3, 2), "tiles_per_s": round(B / dt, 1)}
-print(json.dumps(out))
+    conv = SpectrogramImageConverter(SpectrogramParams(stereo=stereo), "cuda")
+    for n in (1, 2, 4, 8, 16):
+        tiles = torch.from_numpy(np.random.default_rng(n).integers(0, 256, size=(n, 512, 512, 3), dtype=np.uint8)).cuda()
+        for _ in range(3):
+            conv.audio_from_spectrogram_images(tiles, seed=1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        reps = 10
+        for r in range(reps):
+            pcm = conv.audio_from_spectrogram_images(tiles, seed=r)   # includes the D2H copy of the int16 PCM
+        dt = (time.perf_counter() - t0) / reps
+        print(f"{'stereo' if stereo else 'mono'} tiles per call {n:2d}: {dt*1e3:6.2f} ms per call ({n/dt:7.1f} tiles/s) [RFX_GL_LATENCY_MODE={os.environ.get('RFX_GL_LATENCY_MODE','1')}]", flush=True)
