@@ -115,6 +115,7 @@ struct rfx_plan {
   bool fwd_unfused = false;        // debugging override (RFX_FWD_UNFUSED), read once at creation
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
   bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
+  int gl_latency_frames_per_slot = 4;  // ... up to this many frames per resident workgroup slot (RFX_GL_LATENCY_FRAMES)
   bool generic = false;
   GenGeom gg{};
   GenTables gt{};
@@ -207,6 +208,7 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
   if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
   pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : 0;
   if (const char* e = getenv("RFX_GL_LATENCY_MODE")) pl->gl_latency_mode = atoi(e) != 0;
+  if (const char* e = getenv("RFX_GL_LATENCY_FRAMES")) pl->gl_latency_frames_per_slot = atoi(e) > 0 ? atoi(e) : 4;
 #ifdef RFX_TIMING
   if (const char* e = getenv("RFX_TIMING_PTR")) pl->timing = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
@@ -542,7 +544,7 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
 // Small batches take the per-frame kernels (rfx_gl.hip: gl_frame_kernel + gl_fold_kernel): at most four frames per resident
 // workgroup slot, where the run-based kernel (>= 10 frames per workgroup) would leave most of the chip idle.
 static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
-  return plan->gl_latency_mode && (long long)B * T <= 4LL * plan->num_cus * plan->gl_wgs_per_cu;
+  return plan->gl_latency_mode && (long long)B * T <= (long long)plan->gl_latency_frames_per_slot * plan->num_cus * plan->gl_wgs_per_cu;
 }
 
 static void gl_layout(const rfx_plan* plan, int B, int T, size_t& off_audio, size_t& off_scale, size_t& off_frames, size_t& total, int& Lpad) {
