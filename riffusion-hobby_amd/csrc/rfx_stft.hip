@@ -251,13 +251,11 @@ __global__ void __launch_bounds__(256) mel_transpose_kernel(const float* __restr
   __shared__ float tile[64][65];
   const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64, b = blockIdx.z;
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-#pragma unroll
   for (int r = ly; r < 64; r += 4) {
     const int tt = t0 + r;
     tile[r][lx] = tt < T ? in[((size_t)b * T + tt) * Mpad + m0 + lx] : 0.f;  // m0 + lx < Mpad always (Mpad % 64 == 0)
   }
   __syncthreads();
-#pragma unroll
   for (int r = ly; r < 64; r += 4) {
     const int m = m0 + r, tt = t0 + lx;
     if (m < M && tt < T) out[((size_t)b * M + m) * T + tt] = tile[lx][r];
