@@ -85,6 +85,9 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
  * spectrogram_converter.py:62-73, called at :204.
  * d_mag_slots: magnitudes in slot layout; d_angles0_slots: optional injected initial angles
  * (NULL = draw U[0,1) real/imag per bin from `seed`); d_wave_out: (B, rfx_griffinlim_output_samples(plan, T)) float32. */
+/* Two device forms, chosen per call from B*T: the run-based fused kernel (one launch per iteration) for batches, and a
+ * per-frame kernel + fold (two launches per iteration, every frame its own workgroup) for the few-tiles-per-request case;
+ * the workspace query below accounts for whichever the shape will take. */
 size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T);
 /* samples per clip rfx_griffinlim writes for T frames: what torch.istft(center=True, length=None) returns,
  * hop*(T-1), plus one when n_fft is odd */
