@@ -542,11 +542,30 @@ def main():
             "roofline": roofline,
             "stages": extra,
         }
+    # ---- the one-tile-per-request case (reference server.py:152-164): uint8 tile in HBM -> int16 PCM on the host, one call
+    latency = None
+    if rank == 0:
+        from riffusion.spectrogram_image_converter import SpectrogramImageConverter
+
+        latency = {}
+        for name, stereo in (("mono", False), ("stereo", True)):
+            conv = SpectrogramImageConverter(SpectrogramParams(stereo=stereo, num_griffin_lim_iters=args.iters), device=str(dev))
+            one = tiles[:1]
+            for r in range(3):
+                conv.audio_from_spectrogram_images(one, seed=r)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for r in range(10):
+                conv.audio_from_spectrogram_images(one, seed=10 + r)
+            latency[name + "_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+        latency["note"] = "SpectrogramImageConverter.audio_from_spectrogram_images on ONE 512x512 tile, D2H copy of the PCM included (small-batch Griffin-Lim kernels)"
+
     # ---- configs[2] (audio -> mel image) measured in the same run and carried on the same line
     fwd = None
     if not args.no_forward:
         fwd = forward_measure(args, world, rank, dev, distributed, with_cpu=False)
     if rank == 0:
+        out["single_tile_latency"] = latency
         if fwd is not None:
             out["forward"] = {k: fwd[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "stages")}
         if world == 1 and not args.no_cpu_baseline:

@@ -39,6 +39,7 @@ def test_headline_line_small_batch():
     f = d["forward"]
     assert f["unit"] == "images/s" and f["value"] > 0 and f["roofline"]["kernel"] == "rfx::stft_mel_kernel"
     assert {"image_decode_ms", "inverse_mel_ms", "griffinlim_ms", "pcm16_ms"} <= set(d["stages"])
+    assert 0 < d["single_tile_latency"]["mono_ms"] < d["single_tile_latency"]["stereo_ms"] * 1.5
 
 
 def test_distributed_launch_one_rank_keeps_stdout_clean():
