@@ -9,11 +9,13 @@
 //     FFT of length nc, then the classic split  X[k] = (Z[k] + conj Z[nc-k])/2 - i w^k (Z[k] - conj Z[nc-k])/2,
 //     w = exp(-2 pi i / n_fft);  the inverse retraces it;
 //   * n_fft odd: a complex FFT of length nc = n_fft on (x, 0).
-// The complex FFT is a Stockham autosort: one pass per radix R over the nc points, reading buffer A and writing
-// buffer B (both in LDS), pass s combining sub-transforms of length Ns = prod of the earlier radices:
-//     v[q]  = in[j + q nc/R] * W_{Ns R}^{q (j mod Ns)}          j = 0 .. nc/R - 1
-//     y     = DFT_R(v)
-//     out[(j div Ns) Ns R + (j mod Ns) + q Ns] = y[q]
+// The complex FFT runs one pass per radix R over the nc points in LDS, in one of two forms:
+//   * in place (the kernels' default): forward = decimation in frequency - pass s splits blocks of length L into R
+//     sub-blocks of length m = L / R:  y = DFT_R(buf[base + q m]);  buf[base + p m] = y[p] W_L^{i p}  (i = position inside
+//     the sub-block) - leaving the spectrum digit-reversed; inverse = decimation in time over the same (L, m) pairs in
+//     reverse order on digit-reversed input.  One buffer: two workgroups per CU at 48 kHz.
+//   * Stockham autosort between two buffers, pass s combining sub-transforms of length Ns = prod of the earlier radices:
+//       v[q] = in[j + q nc/R] * W_{Ns R}^{q (j mod Ns)},  y = DFT_R(v),  out[(j div Ns) Ns R + (j mod Ns) + q Ns] = y[q]
 // Twiddles W_nc^t come from a two-level table (W^t = hi[t >> 7] * lo[t & 127], both small enough to sit in LDS next
 // to the two buffers), the R-th roots of a pass are looked up once per thread and pass.
 #pragma once
