@@ -58,6 +58,8 @@ def parse():
                          "decode-stereo64 = configs[3] (512 stereo tiles, Griffin-Lim 64, sharded over the ranks)")
     ap.add_argument("--global-clips", type=int, default=512, help="decode-stereo64: clips in the sharded batch")
     ap.add_argument("--no-forward", action="store_true", help="skip the embedded configs[2] forward measurement")
+    ap.add_argument("--gather", choices=["none", "rank0", "all"], default="none",
+                    help="decode-stereo64: which clips a rank returns (own shard / everything on rank 0 / everything everywhere)")
     return ap.parse_args()
 
 
@@ -317,10 +319,14 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
 
 def stereo64_main(args, world, rank, dev, distributed):
     """BASELINE.json configs[3]: a fixed batch of `--global-clips` stereo 512x512 tiles, Griffin-Lim 64, sharded over the
-    ranks through the product entry point (SpectrogramImageConverter.audio_from_spectrogram_images(group=...)): every
-    rank decodes shard_range(N, world, rank) and the int16 PCM is all_gathered over RCCL."""
+    ranks through the product entry point (SpectrogramImageConverter.audio_from_spectrogram_images(group=..., gather=...)):
+    every rank decodes shard_range(N, world, rank) and copies ITS clips to (pinned) host memory chunk by chunk behind the
+    compute (`--gather none`, the default: no data-path collective); `--gather rank0` / `all` add one RCCL
+    gather / all_gather_into_tensor of the int16 PCM.  After the timed region a stage leg splits one step into
+    compute / device-to-host / collective and predicts the 8-GPU speed-up from those parts."""
     import torch.distributed as dist
 
+    from riffusion import batch_shard
     from riffusion.spectrogram_image_converter import SpectrogramImageConverter
     from riffusion.spectrogram_params import SpectrogramParams
 
@@ -330,6 +336,7 @@ def stereo64_main(args, world, rank, dev, distributed):
     rng = np.random.default_rng(20240807)  # the SAME full batch on every rank
     tiles = torch.from_numpy(rng.integers(0, 256, size=(N, N_MELS, N_FRAMES, 3), dtype=np.uint8)).to(dev)
     group = dist.group.WORLD if distributed else None
+    L = HOP * (N_FRAMES - 1)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -338,32 +345,88 @@ def stereo64_main(args, world, rank, dev, distributed):
         torch.cuda.synchronize(dev)
 
     for w in range(args.warmup):
-        conv.audio_from_spectrogram_images(tiles[: 64 * world], seed=w, group=group)
+        conv.audio_from_spectrogram_images(tiles, seed=w, group=group, gather=args.gather)  # same shapes as the timed steps (pinned blocks cached)
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        pcm = conv.audio_from_spectrogram_images(tiles, seed=100 + k, group=group)
+        pcm = conv.audio_from_spectrogram_images(tiles, seed=100 + k, group=group, gather=args.gather)
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    assert pcm.shape == (N, HOP * (N_FRAMES - 1), 2) and pcm.dtype == np.int16
+    lo, hi = batch_shard.result_rows(N, group, args.gather)
+    assert pcm.shape == (hi - lo, L, 2) and pcm.dtype == np.int16
+    del pcm
+
+    # ---- stage leg (outside the timed region, every rank takes part in the collective) ----------------------------------
+    def wall(fn, reps=2):
+        best = float("inf")
+        for _ in range(reps):
+            sync_all()
+            t = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t)
+        return best * 1e3
+
+    mylo, myhi = batch_shard.shard_range(N, world, rank)
+    n_mine = myhi - mylo
+    compute_ms = wall(lambda: conv.audio_from_spectrogram_images(tiles, seed=7, group=group, gather="none", return_device=True))
+    host_ms = wall(lambda: conv.audio_from_spectrogram_images(tiles, seed=7, group=group, gather="none"))
+    shard = torch.zeros((n_mine, L, 2), dtype=torch.int16, device=dev)
+    pinned = torch.empty(shard.shape, dtype=torch.int16, pin_memory=True)
+    d2h_raw_ms = wall(lambda: pinned.copy_(shard, non_blocking=True))
+    gather_ms = {}
+    if distributed:
+        gather_ms["all_gather_into_tensor_ms"] = wall(lambda: batch_shard.gather_clips(shard, N, group))
+        gather_ms["gather_rank0_ms"] = wall(lambda: batch_shard.gather_clips(shard, N, group, dst=0))
+    # what one eighth of the batch costs on this GPU: the per-rank compute of an 8-GPU run of the same N
+    n8 = -(-N // 8)
+    eighth_ms = wall(lambda: conv.audio_from_spectrogram_images(tiles[:n8], seed=9, gather="none")) if world == 1 and N >= 8 else None
+    del shard, pinned
     if rank != 0:
         return None
+    ms_per_step = elapsed / args.steps * 1e3
     tiles_per_s = N * args.steps / elapsed
-    return {
+    pcm_mb = N * L * 2 * 2 / 1e6
+    stages = {"compute_ms": round(compute_ms, 3), "compute_plus_d2h_ms": round(host_ms, 3),
+              "d2h_exposed_ms": round(max(0.0, host_ms - compute_ms), 3),
+              "d2h_own_shard_raw_ms": round(d2h_raw_ms, 3), "own_shard_mb": round(n_mine * L * 4 / 1e6, 1), **{k: round(v, 3) for k, v in gather_ms.items()},
+              "note": "rank 0, best of 2, wall clock between device syncs: compute = own shard with return_device=True; compute_plus_d2h = the same "
+                      "call returning host PCM (chunk copies on a side stream behind the compute, pinned memory); d2h_own_shard_raw = the whole "
+                      "shard in one un-overlapped pinned copy; collectives move the own shard (int16, as bytes) into one preallocated tensor"}
+    out = {
         "metric": "stereo_spectrogram_tiles_per_sec_griffinlim64", "value": round(tiles_per_s, 2), "unit": "tiles/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} synthetic stereo 512x512 uint8 tiles -> image decode -> InverseMelScale SGD-200 -> Griffin-Lim 64 "
-                               "-> int16 PCM (BASELINE.json configs[3]), sharded over the ranks with shard_range, PCM all_gathered over "
-                               "RCCL and copied to the host (the product entry point returns numpy)",
-                   "global_batch": N, "clips_per_gpu": -(-N // world), "griffin_lim_iters": 64,
-                   "parallelism": f"clips sharded over {world} GPU(s); one all_gather of {N * HOP * (N_FRAMES - 1) * 4 / 1e6:.0f} MB int16 PCM"},
-        "audio_sec_per_sec": round(tiles_per_s * HOP * (N_FRAMES - 1) / SR, 1),
+                               f"-> int16 PCM in host memory (BASELINE.json configs[3]), clips sharded over the ranks with shard_range, gather={args.gather!r}"
+                               + {"none": " (every rank returns its own clips; no data-path collective)",
+                                  "rank0": f" (one RCCL gather of {pcm_mb:.0f} MB int16 PCM to rank 0)",
+                                  "all": f" (one RCCL all_gather_into_tensor of {pcm_mb:.0f} MB int16 PCM)"}[args.gather],
+                   "global_batch": N, "clips_per_gpu": -(-N // world), "griffin_lim_iters": 64, "gather": args.gather,
+                   "parallelism": f"clips sharded over {world} GPU(s)"},
+        "audio_sec_per_sec": round(tiles_per_s * L / SR, 1),
+        "stages": stages,
     }
+    if eighth_ms is not None:
+        # 8-GPU step = the slowest rank's shard (N/8 clips incl. its overlapped D2H) + the collective, if one was asked for.
+        # The collective is priced from the xGMI figures of MI355X_MICROARCH.md (7 links x ~153 GB/s per GPU, ~75 % achievable):
+        # all_gather: every rank receives 7 shards over 7 links in parallel; gather: rank 0 receives 7 shards, one per link.
+        link_gbs = 153.0 * 0.75
+        shard_mb = n8 * L * 4 / 1e6
+        coll_ms = 0.0 if args.gather == "none" else shard_mb / link_gbs
+        full_d2h_ms = 0.0 if args.gather == "none" else d2h_raw_ms * (7.0 / 8.0)  # the 7 foreign shards cross PCIe after the collective
+        pred8 = eighth_ms + coll_ms + full_d2h_ms
+        out["predicted_speedup_8"] = {"value": round(ms_per_step / pred8, 2), "t1_ms": round(ms_per_step, 3), "t8_ms": round(pred8, 3),
+                                      "per_rank_compute_plus_own_d2h_ms": round(eighth_ms, 3), "collective_ms_model": round(coll_ms, 3),
+                                      "foreign_shards_d2h_ms_model": round(full_d2h_ms, 3),
+                                      "note": f"t8 = this GPU running {n8} of the {N} clips through the same entry point (measured) + the gather={args.gather!r} "
+                                              "collective at 0.75 x 153 GB/s per xGMI link (model) + the pinned copy of the foreign shards (measured rate); "
+                                              "the driver's SCALE run is the measurement, this is the budget"}
+    return out
 
 
 def main():

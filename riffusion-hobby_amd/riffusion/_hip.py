@@ -441,14 +441,20 @@ class Plan:
         check(self.lib.rfx_image_encode_u8(mel.data_ptr(), N, M, Tn, int(stereo), thresholds.data_ptr(), mx.data_ptr(), img.data_ptr(), self._stream()))
         return img, mx
 
-    def pcm16(self, wave: torch.Tensor, channels: int, normalize: bool = True):
-        """(N*C, L) float32 -> ((N, L, C) int16, per-clip peak (N,))."""
+    def pcm16(self, wave: torch.Tensor, channels: int, normalize: bool = True, out: T.Optional[torch.Tensor] = None):
+        """(N*C, L) float32 -> ((N, L, C) int16, per-clip peak (N,)).  `out`: preallocated contiguous (N, L, C) int16
+        destination on this device (e.g. the rows of a batch-wide result), otherwise a fresh tensor."""
         wave = self._chk(wave, torch.float32)
         NC, L = wave.shape
         if NC % channels:
             raise ValueError("batch must be a multiple of the channel count")
         N = NC // channels
-        pcm = torch.empty((N, L, channels), dtype=torch.int16, device=wave.device)
+        if out is not None:
+            if out.device != self.device or out.dtype != torch.int16 or tuple(out.shape) != (N, L, channels) or not out.is_contiguous():
+                raise ValueError(f"out must be a contiguous int16 tensor of shape {(N, L, channels)} on {self.device}")
+            pcm = out
+        else:
+            pcm = torch.empty((N, L, channels), dtype=torch.int16, device=wave.device)
         peak = torch.zeros((N,), dtype=torch.float32, device=wave.device)
         check(self.lib.rfx_pcm16(wave.data_ptr(), N, channels, L, int(normalize), peak.data_ptr(), pcm.data_ptr(), self._stream()))
         return pcm, peak

@@ -2,14 +2,28 @@
 Sharding of independent clips over the GPUs of a node (one process per GPU, torch.distributed).
 
 Clips never depend on each other: every rank converts its contiguous slice of the
-batch with no data-path collective; the only collective is an optional all_gather of the int16 PCM
-when one consumer needs the whole batch.  Backend "nccl" is RCCL on ROCm; the CPU tests run the same
-code over "gloo".
+batch with no data-path collective.  What happens to the per-rank results afterwards is the
+caller's choice (`gather=`):
+
+    "none"   nothing: every rank keeps (and returns) its own shard - the reference's consumers want
+             host audio for THEIR clips (server.py:159-183, cli.py:172-204 writes one file per clip)
+    "rank0"  one `gather` to the group's rank 0 (one consumer needs the whole batch); the other
+             ranks keep their own shard
+    "all"    one `all_gather_into_tensor`: every rank ends up with the whole batch
+
+Both collectives move the shards into ONE preallocated tensor (no list of parts + cat).  Backend
+"nccl" is RCCL on ROCm; the CPU tests run the same code over "gloo".
+
+`ChunkSink` is the other half of a scalable batch call: a rank's shard is produced chunk by chunk
+(bounded working set), and each finished chunk is copied to a pinned host buffer on a side stream
+while the next chunk computes, so the device-to-host copy is off the critical path.
 """
 import typing as T
 
 import torch
 import torch.distributed as dist
+
+GATHER_MODES = ("all", "rank0", "none")
 
 
 def shard_range(n_items: int, world_size: int, rank: int) -> T.Tuple[int, int]:
@@ -21,37 +35,131 @@ def shard_range(n_items: int, world_size: int, rank: int) -> T.Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_clips(local: torch.Tensor, n_items: int, group: T.Optional[T.Any] = None) -> torch.Tensor:
-    """all_gather of per-rank results (clips on dim 0, ragged by at most one) into the full batch, rank order."""
+def _resolve_group(group: T.Any) -> T.Any:
+    """`True` means the default group."""
+    return None if group is True else group
+
+
+def gather_clips(
+    local: torch.Tensor, n_items: int, group: T.Optional[T.Any] = None, dst: T.Optional[int] = None
+) -> T.Optional[torch.Tensor]:
+    """
+    Per-rank results (clips on dim 0, ragged by at most one) -> the full batch in rank order.
+
+    dst=None: all_gather, every rank returns the full batch.  dst=r (group rank): gather, only rank r
+    returns it (the others get None).  The shards land in one preallocated tensor; when the clips
+    divide evenly over the ranks that tensor IS the result (no further copy).
+    """
     world = dist.get_world_size(group)
     if world == 1:
         return local
+    rank = dist.get_rank(group)
     sizes = [shard_range(n_items, world, r) for r in range(world)]
     longest = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    # moved as raw bytes: every backend carries uint8, not every backend carries int16
-    raw = pad.contiguous().view(torch.uint8).reshape(-1)
-    parts = [torch.empty_like(raw) for _ in range(world)]
-    dist.all_gather(parts, raw, group=group)
-    parts = [p.view(local.dtype).reshape(pad.shape) for p in parts]
-    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+    row_shape = tuple(local.shape[1:])
+    if local.shape[0] == longest and local.is_contiguous():
+        mine = local
+    else:
+        mine = torch.zeros((longest,) + row_shape, dtype=local.dtype, device=local.device)
+        mine[: local.shape[0]] = local
+    # moved as raw bytes: every backend carries uint8, RCCL has no int16
+    raw = mine.view(torch.uint8).reshape(-1)
+    receiver = dst is None or rank == dst
+    full = torch.empty((world * longest,) + row_shape, dtype=local.dtype, device=local.device) if receiver else None
+    if dst is None:
+        dist.all_gather_into_tensor(full.view(torch.uint8).reshape(-1), raw, group=group)
+    else:
+        parts = list(full.view(torch.uint8).reshape(world, -1).unbind(0)) if receiver else None
+        dist.gather(raw, parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+    if not receiver:
+        return None
+    if all(hi - lo == longest for lo, hi in sizes):
+        return full
+    rows = full.reshape((world, longest) + row_shape)
+    return torch.cat([rows[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
 def sharded_map(
-    convert: T.Callable[[int, int], torch.Tensor], n_items: int, group: T.Any = None
+    convert: T.Callable[[int, int], torch.Tensor], n_items: int, group: T.Any = None, gather: str = "all"
 ) -> torch.Tensor:
     """
     The multi-GPU form of a batch call: rank r runs `convert(lo, hi)` on its slice [lo, hi) of the
-    clips (it must return a tensor with hi - lo rows, also when the slice is empty) and the per-rank
-    results are all_gathered into the full batch on every rank.  `group=None` runs the whole batch
-    locally (no process group needed); `group=True` means the default group.
+    clips (it must return a tensor with hi - lo rows, also when the slice is empty); `gather` says
+    who receives what (module docstring).  `group=None` runs the whole batch locally (no process
+    group needed); `group=True` means the default group.
     """
+    if gather not in GATHER_MODES:
+        raise ValueError(f"gather must be one of {GATHER_MODES}, got {gather!r}")
     if group is None:
         return convert(0, n_items)
-    pg = None if group is True else group
+    pg = _resolve_group(group)
     lo, hi = shard_range(n_items, dist.get_world_size(pg), dist.get_rank(pg))
     local = convert(lo, hi)
     if local.shape[0] != hi - lo:
         raise ValueError(f"convert({lo}, {hi}) returned {local.shape[0]} rows")
-    return gather_clips(local, n_items, pg)
+    if gather == "none":
+        return local
+    full = gather_clips(local, n_items, pg, dst=None if gather == "all" else 0)
+    return local if full is None else full
+
+
+def result_rows(n_items: int, group: T.Any = None, gather: str = "all") -> T.Tuple[int, int]:
+    """Which clips [lo, hi) of the batch a `sharded_map(..., group, gather)` call returns ON THIS RANK."""
+    if group is None:
+        return 0, n_items
+    pg = _resolve_group(group)
+    world, rank = dist.get_world_size(pg), dist.get_rank(pg)
+    if gather == "all" or (gather == "rank0" and rank == 0):
+        return 0, n_items
+    return shard_range(n_items, world, rank)
+
+
+class ChunkSink:
+    """
+    Destination of a shard that is produced chunk by chunk.
+
+    to_host=False: one preallocated device tensor; `put` copies a chunk into its rows (stream order).
+    to_host=True:  one pinned host tensor; `put` queues the chunk's device-to-host copy on a SIDE
+                   stream behind an event on the compute stream, so the copy of chunk k runs while
+                   chunk k+1 computes; `finish` waits for the side stream.  The pinned block comes
+                   from torch's caching host allocator (first call pays the registration, later calls
+                   reuse it) and is owned by the returned tensor - a fresh object per call, as the
+                   reference's callers expect.
+    On a machine without a GPU (the CPU tests) both forms degrade to plain copies.
+    """
+
+    def __init__(self, rows: int, row_shape: T.Sequence[int], dtype: torch.dtype, device: torch.device, to_host: bool):
+        self.to_host = to_host
+        self.cuda = torch.device(device).type == "cuda"
+        shape = (rows,) + tuple(row_shape)
+        if to_host:
+            self.out = torch.empty(shape, dtype=dtype, pin_memory=self.cuda)
+            self.side = torch.cuda.Stream(device) if self.cuda else None
+        else:
+            self.out = torch.empty(shape, dtype=dtype, device=device)
+            self.side = None
+        self.device = device
+
+    def rows(self, a: int, b: int) -> T.Optional[torch.Tensor]:
+        """Device view a producer may write rows [a, b) into directly (None when the sink is on the host)."""
+        return None if self.to_host else self.out[a:b]
+
+    def put(self, a: int, b: int, chunk: torch.Tensor) -> None:
+        if not self.to_host:
+            if chunk.data_ptr() != self.out[a:b].data_ptr():
+                self.out[a:b].copy_(chunk)
+            return
+        if self.side is None:
+            self.out[a:b].copy_(chunk)
+            return
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self.side.wait_event(done)
+        with torch.cuda.stream(self.side):
+            self.out[a:b].copy_(chunk, non_blocking=True)
+        chunk.record_stream(self.side)  # the allocator must not hand the chunk out again before the copy has run
+
+    def finish(self) -> torch.Tensor:
+        if self.side is not None:
+            self.side.synchronize()
+        return self.out

@@ -102,44 +102,73 @@ class SpectrogramImageConverter:
         return_waveform: bool = False,
         group: T.Any = None,
         tiles_per_call: int = 64,
-    ) -> np.ndarray:
+        gather: str = "all",
+        return_device: bool = False,
+    ) -> T.Union[np.ndarray, torch.Tensor]:
         """
-        (N, H, W, 3) RGB tiles -> (N, samples, C) int16 PCM (or the float waveforms).
+        (N, H, W, 3) RGB tiles -> (n, samples, C) int16 PCM (or, with `return_waveform`, the (n, C, samples)
+        float waveforms); a numpy array on the host, or with `return_device=True` a tensor that never left the GPU.
 
         `images_u8` is a uint8 array / tensor on any device, or the diffusion pipeline's float [0, 1]
-        NHWC tensor (quantised here like `numpy_to_pil`, see `quantize_pipeline_images`).
+        NHWC tensor (quantised here like `numpy_to_pil`, see `quantize_pipeline_images`; a float input
+        with values above 1 is refused - pass pixel values as uint8).
 
         `group`: a `torch.distributed` process group (or True for the default group).  Every rank
-        passes the SAME full batch; rank r converts clips `shard_range(N, world, r)` on its own GPU and
-        the int16 PCM is all_gathered, so every rank returns the full (N, samples, C) result.  A clip's
-        channels never leave their rank (they share the SGD loss mean and the peak normalisation).
+        passes the SAME full batch; rank r converts clips `shard_range(N, world, r)` on its own GPU
+        (a clip's channels never leave their rank: they share the SGD loss mean and the peak
+        normalisation), `tiles_per_call` clips at a time.  `gather` says which clips a rank RETURNS
+        (`batch_shard.result_rows`):
+            "all"   (default) the whole batch on every rank - one RCCL all_gather_into_tensor of the int16 PCM;
+            "rank0" the whole batch on the group's rank 0 (one RCCL gather), the own shard elsewhere;
+            "none"  the own shard only, no collective at all (each rank writes / serves its own clips).
+        Host results are staged through pinned memory; without a collective each chunk's device-to-host
+        copy runs on a side stream while the next chunk computes (`batch_shard.ChunkSink`).
         Like the reference, the two random initialisations are not reproducible across different
         shardings (each call draws its own streams from `seed`).
         """
         from riffusion import batch_shard
 
+        if tiles_per_call < 1:
+            raise ValueError(f"tiles_per_call must be >= 1, got {tiles_per_call}")
+        if gather not in batch_shard.GATHER_MODES:
+            raise ValueError(f"gather must be one of {batch_shard.GATHER_MODES}, got {gather!r}")
         conv = self.converter
         plan = conv._plan()
         imgs = torch.as_tensor(np.ascontiguousarray(images_u8) if isinstance(images_u8, np.ndarray) else images_u8)
         if imgs.is_floating_point():
+            if imgs.numel() and float(imgs.max()) > 1.0 + 1e-6:
+                raise ValueError("float images must be the pipeline's [0, 1] output (riffusion_pipeline.py:427-431); "
+                                 "pass 0..255 pixel values as uint8")
             imgs = self.quantize_pipeline_images(imgs)
         n_total = imgs.shape[0]
         C = 2 if self.p.stereo else 1
+        L = plan.lib.rfx_griffinlim_output_samples(plan.handle, int(imgs.shape[2]))
         base_seed = conv._seed(seed)
         lut = torch.from_numpy(image_util.decode_lut(float(self.p.power_for_image), float(max_value))).to(plan.device)
+        row_shape, dtype = ((C, L), torch.float32) if return_waveform else ((L, C), torch.int16)
+
+        pg = None if group is None else batch_shard._resolve_group(group)
+        world = 1 if group is None else torch.distributed.get_world_size(pg)
+        # a shard that takes part in a collective stays on the device until the collective has run
+        collective = world > 1 and gather != "none"
 
         def convert(lo: int, hi: int) -> torch.Tensor:
-            outs = []
+            sink = batch_shard.ChunkSink(hi - lo, row_shape, dtype, plan.device, to_host=not (collective or return_device))
             for a in range(lo, hi, tiles_per_call):  # bounded working set: |S| alone is 19 MB per tile-channel
                 b = min(hi, a + tiles_per_call)
                 mel = plan.image_decode(imgs[a:b].to(plan.device), self.p.stereo, lut)
                 wave = conv.waveform_from_mel_amplitudes(mel, seed=base_seed + 2 * a, channels_per_clip=C)
-                outs.append(wave.reshape(b - a, C, -1) if return_waveform else plan.pcm16(wave, channels=C, normalize=True)[0])
-            if outs:
-                return torch.cat(outs, dim=0)
-            L = plan.lib.rfx_griffinlim_output_samples(plan.handle, int(imgs.shape[2]))  # a rank with an empty shard still joins the gather
-            return torch.empty((0, C, L) if return_waveform else (0, L, C),
-                               dtype=torch.float32 if return_waveform else torch.int16, device=plan.device)
+                if return_waveform:
+                    sink.put(a - lo, b - lo, wave.reshape(b - a, C, -1))
+                else:
+                    dst = sink.rows(a - lo, b - lo)  # device sink: the PCM kernel writes the batch rows in place
+                    sink.put(a - lo, b - lo, plan.pcm16(wave, channels=C, normalize=True, out=dst)[0])
+            return sink.finish()  # a rank with an empty shard still joins the collective with 0 rows
 
-        local = batch_shard.sharded_map(convert, n_total, group)
-        return local.cpu().numpy()
+        result = batch_shard.sharded_map(convert, n_total, group, gather)
+        if return_device or not result.is_cuda:
+            return result if return_device else result.numpy()
+        host = torch.empty(result.shape, dtype=result.dtype, pin_memory=True)  # gathered batch: one pinned copy
+        host.copy_(result, non_blocking=True)
+        torch.cuda.current_stream(plan.device).synchronize()
+        return host.numpy()

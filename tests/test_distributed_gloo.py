@@ -48,7 +48,7 @@ def test_two_rank_gather(n_items):
 
 
 def _map_worker(rank, world, port, n_items):
-    from riffusion.batch_shard import sharded_map
+    from riffusion.batch_shard import result_rows, sharded_map
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -60,8 +60,28 @@ def _map_worker(rank, world, port, n_items):
 
     full = sharded_map(convert, n_items, dist.group.WORLD)
     assert calls == [shard_range(n_items, world, rank)]  # each rank converts only its own slice, once
+    calls.clear()
     assert full.shape == (n_items, 4, 1) and torch.equal(full[:, 0, 0], torch.arange(n_items, dtype=torch.int16))
     assert torch.equal(sharded_map(convert, n_items, True), full)  # True = default group
+    # gather="none": the own shard only, no collective; gather="rank0": the whole batch on rank 0, own shard elsewhere
+    lo, hi = shard_range(n_items, world, rank)
+    own = sharded_map(convert, n_items, dist.group.WORLD, gather="none")
+    assert own.shape == (hi - lo, 4, 1) and torch.equal(own[:, 0, 0], torch.arange(lo, hi, dtype=torch.int16))
+    assert result_rows(n_items, dist.group.WORLD, "none") == (lo, hi)
+    r0 = sharded_map(convert, n_items, dist.group.WORLD, gather="rank0")
+    assert torch.equal(r0, full if rank == 0 else own)
+    assert result_rows(n_items, dist.group.WORLD, "rank0") == ((0, n_items) if rank == 0 else (lo, hi))
+    assert result_rows(n_items, dist.group.WORLD, "all") == (0, n_items) and result_rows(n_items) == (0, n_items)
+    with pytest.raises(ValueError):
+        sharded_map(convert, n_items, dist.group.WORLD, gather="everyone")
+    # a sub-group whose rank 0 is global rank 1: "rank0" means the GROUP's first rank
+    sub = dist.new_group([1, 0]) if world == 2 else None
+    if sub is not None:
+        g = sharded_map(convert, n_items, sub, gather="rank0")
+        glo, ghi = shard_range(n_items, 2, dist.get_rank(sub))
+        assert g.shape[0] == (n_items if dist.get_rank(sub) == 0 else ghi - glo)
+        assert torch.equal(g[:, 0, 0], torch.arange(n_items, dtype=torch.int16) if dist.get_rank(sub) == 0
+                           else torch.arange(glo, ghi, dtype=torch.int16))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,3 +101,22 @@ def test_sharded_map_without_group_runs_locally():
 
     out = sharded_map(lambda lo, hi: torch.arange(lo, hi)[:, None], 5, None)
     assert out.shape == (5, 1)
+
+
+def test_chunk_sink_on_cpu_and_gather_into_one_tensor():
+    """ChunkSink degrades to plain copies without a GPU; an even split is gathered without a compaction copy."""
+    from riffusion.batch_shard import ChunkSink
+
+    for to_host in (False, True):
+        sink = ChunkSink(5, (3, 2), torch.int16, torch.device("cpu"), to_host=to_host)
+        for a in range(0, 5, 2):
+            b = min(5, a + 2)
+            dst = sink.rows(a, b)
+            chunk = torch.full((b - a, 3, 2), a, dtype=torch.int16)
+            if dst is not None:
+                dst.copy_(chunk)
+                chunk = dst
+            sink.put(a, b, chunk)
+        out = sink.finish()
+        assert out.shape == (5, 3, 2) and out[:, 0, 0].tolist() == [0, 0, 2, 2, 4]
+    assert ChunkSink(0, (3, 2), torch.int16, torch.device("cpu"), to_host=True).finish().shape == (0, 3, 2)
