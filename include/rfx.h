@@ -44,7 +44,7 @@ typedef struct {
   int32_t sample_rate;
   int32_t n_fft;        /* 17640 at 44.1 kHz: that geometry (with win 4410, hop 441) runs on the specialised engine, */
   int32_t win_length;   /* 4410     every other one (48 kHz: 19200 / 4800 / 480, 22.05 kHz: 8820 / 2205 / 220, ...) on */
-  int32_t hop_length;   /* 441      the generic Stockham engine: same entry points, same semantics, about 3x slower   */
+  int32_t hop_length;   /* 441      the generic mixed-radix engine: same entry points and semantics   */
   int32_t n_mels;       /* num_frequencies */
   int32_t max_mel_iters;
 } rfx_params;
@@ -67,6 +67,31 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
                     rfx_plan** out_plan);
 int rfx_plan_destroy(rfx_plan* plan);
 
+/* Which of the two Griffin-Lim device forms of the specialised engine a call takes (see rfx_griffinlim below). */
+typedef enum {
+  RFX_GL_FORM_AUTO = 0,   /* per call, from B*T: frames for the few-tiles-per-request case, runs for batches */
+  RFX_GL_FORM_RUNS = 1,   /* always the run-based fused kernel (one launch per iteration) */
+  RFX_GL_FORM_FRAMES = 2  /* always the per-frame kernel + fold (two launches per iteration) */
+} rfx_gl_form;
+
+/* Plan-creation options.  Set struct_size = sizeof(rfx_plan_options); zero in every other field means "default". */
+typedef struct {
+  uint32_t struct_size;
+  int32_t gl_form;             /* rfx_gl_form */
+  int32_t gl_frames_per_slot;  /* RFX_GL_FORM_AUTO takes the per-frame form up to this many frames per resident
+                                  workgroup slot of the chip (0 = default, 4: the measured crossover, 8 tiles per call) */
+} rfx_plan_options;
+
+/* rfx_plan_create with options (NULL = defaults = rfx_plan_create). */
+int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
+                       const rfx_plan_options* options, rfx_plan** out_plan);
+/* the form (RFX_GL_FORM_RUNS / _FRAMES) an rfx_griffinlim call of B x T frames takes on this plan */
+int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
+/* frames torch.stft(center=True, pad_mode="reflect") makes of Lw samples: 1 + (Lw + 2*(n_fft/2) - n_fft) / hop, i.e.
+ * 1 + Lw/hop for even n_fft and 1 + (Lw-1)/hop for odd n_fft; 0 when Lw <= n_fft/2 (the reference raises there).
+ * Every forward entry point below produces exactly this many frames. */
+int rfx_stft_frames(const rfx_plan* plan, int Lw);
+
 /* ---- layout converters ------------------------------------------------------------------- */
 /* (B, n_stft, T) float32 magnitudes -> slots (float32) */
 int rfx_pack_magnitudes(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_slots, void* stream);
@@ -77,7 +102,7 @@ int rfx_unpack_complex(const rfx_plan* plan, const void* d_slots, int B, int T, 
 
 /* ---- forward: torchaudio.transforms.Spectrogram(power=None) [+ torch.abs] ------------------
  * spectrogram_converter.py:179 (+ :182).  d_wave: (B, Lw) float32, Lw > n_fft/2.
- * T = 1 + Lw / hop.  Either output may be NULL. */
+ * T = rfx_stft_frames(plan, Lw).  Either output may be NULL. */
 int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mag_slots, void* d_spec_slots,
              void* stream);
 
@@ -109,7 +134,7 @@ int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int
 
 /* ---- forward: mel_amplitudes_from_waveform, spectrogram_converter.py:165-185
  * Spectrogram(power=None) -> torch.abs -> MelScale (matmul with the filterbank, on the fp32 MFMA).
- * d_wave (B, Lw) float32 -> d_mel_out (B, n_mels, T) float32, T = 1 + Lw / hop. */
+ * d_wave (B, Lw) float32 -> d_mel_out (B, n_mels, T) float32, T = rfx_stft_frames(plan, Lw). */
 size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw);
 int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
                           size_t workspace_bytes, void* stream);

@@ -116,6 +116,7 @@ struct rfx_plan {
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
   bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
   int gl_latency_frames_per_slot = 4;  // ... up to this many frames per resident workgroup slot (RFX_GL_LATENCY_FRAMES)
+  int gl_form = RFX_GL_FORM_AUTO;      // rfx_plan_options.gl_form
   bool generic = false;
   GenGeom gg{};
   GenTables gt{};
@@ -150,6 +151,16 @@ int rfx_frame_stride(void) { return kFrameStride; }
 int rfx_num_bins(void) { return kBins; }
 int rfx_plan_frame_stride(const rfx_plan* plan) { return plan ? plan->frame_stride : 0; }
 int rfx_plan_is_generic(const rfx_plan* plan) { return plan && plan->generic ? 1 : 0; }
+int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
+// torch.stft(center=True): the signal is reflect-padded by n_fft/2 on both sides, so a waveform of Lw samples gives
+// 1 + (Lw + 2*(n_fft/2) - n_fft) / hop frames: 1 + Lw/hop for even n_fft, 1 + (Lw - 1)/hop for odd n_fft
+static int stft_frames(const rfx_plan* plan, int Lw) {
+  return 1 + (Lw + 2 * (plan->p.n_fft / 2) - plan->p.n_fft) / plan->p.hop_length;
+}
+int rfx_stft_frames(const rfx_plan* plan, int Lw) {
+  if (!plan || Lw <= plan->p.n_fft / 2) return 0;
+  return stft_frames(plan, Lw);
+}
 int rfx_griffinlim_output_samples(const rfx_plan* plan, int T) {
   if (!plan || T < 1) return 0;
   return plan->p.hop_length * (T - 1) + (plan->p.n_fft & 1);
@@ -159,7 +170,21 @@ int rfx_plan_destroy(rfx_plan* plan);
 
 int rfx_plan_create(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
                     rfx_plan** out_plan) {
+  return rfx_plan_create_ex(params, h_window, h_melfb, device, nullptr, out_plan);
+}
+
+int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
+                       const rfx_plan_options* options, rfx_plan** out_plan) {
   if (!params || !out_plan || !h_window) return fail(RFX_ERR_INVALID, "rfx_plan_create: null argument");
+  rfx_plan_options opt{};
+  opt.struct_size = sizeof(rfx_plan_options);
+  if (options) {
+    if (options->struct_size < 2 * sizeof(uint32_t) || options->struct_size > sizeof(rfx_plan_options))
+      return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: options->struct_size does not describe an rfx_plan_options this library knows");
+    memcpy(&opt, options, options->struct_size);
+    if (opt.gl_form < RFX_GL_FORM_AUTO || opt.gl_form > RFX_GL_FORM_FRAMES || opt.gl_frames_per_slot < 0)
+      return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: gl_form must be RFX_GL_FORM_AUTO / _RUNS / _FRAMES, gl_frames_per_slot >= 0");
+  }
   const bool generic = params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop ||
                        getenv("RFX_FORCE_GENERIC") != nullptr;
   GenGeom gg{};
@@ -207,8 +232,12 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
   if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
   pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : 0;
+  // which Griffin-Lim device form a call takes: the options of rfx_plan_create_ex decide; the environment (read here, once)
+  // only changes what RFX_GL_FORM_AUTO / the default threshold mean, for experiments
   if (const char* e = getenv("RFX_GL_LATENCY_MODE")) pl->gl_latency_mode = atoi(e) != 0;
   if (const char* e = getenv("RFX_GL_LATENCY_FRAMES")) pl->gl_latency_frames_per_slot = atoi(e) > 0 ? atoi(e) : 4;
+  pl->gl_form = opt.gl_form;
+  if (opt.gl_frames_per_slot > 0) pl->gl_latency_frames_per_slot = opt.gl_frames_per_slot;
 #ifdef RFX_TIMING
   if (const char* e = getenv("RFX_TIMING_PTR")) pl->timing = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
@@ -514,7 +543,7 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
     g.mag = d_mag_slots;
     g.spec = (cf*)d_spec_slots;
     g.B = B;
-    g.T = 1 + Lw / plan->gg.hop;
+    g.T = stft_frames(plan, Lw);
     g.Lw = Lw;
     if (d_mag_slots) RFX_HIP(launch_gen_stft(0, g, plan->num_cus, (hipStream_t)stream));
     if (d_spec_slots) RFX_HIP(launch_gen_stft(1, g, plan->num_cus, (hipStream_t)stream));
@@ -544,7 +573,15 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
 // Small batches take the per-frame kernels (rfx_gl.hip: gl_frame_kernel + gl_fold_kernel): at most four frames per resident
 // workgroup slot, where the run-based kernel (>= 10 frames per workgroup) would leave most of the chip idle.
 static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
+  if (plan->gl_form == RFX_GL_FORM_RUNS) return false;
+  if (plan->gl_form == RFX_GL_FORM_FRAMES) return true;
   return plan->gl_latency_mode && (long long)B * T <= (long long)plan->gl_latency_frames_per_slot * plan->num_cus * plan->gl_wgs_per_cu;
+}
+
+int rfx_griffinlim_form(const rfx_plan* plan, int B, int T) {
+  if (!plan || B <= 0 || T < 2) return RFX_GL_FORM_AUTO;
+  if (plan->generic) return RFX_GL_FORM_FRAMES;  // the generic engine has one form: frame kernels + fold
+  return gl_use_latency_mode(plan, B, T) ? RFX_GL_FORM_FRAMES : RFX_GL_FORM_RUNS;
 }
 
 static void gl_layout(const rfx_plan* plan, int B, int T, size_t& off_audio, size_t& off_scale, size_t& off_frames, size_t& total, int& Lpad) {
@@ -808,7 +845,7 @@ int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int
 
 size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw) {
   if (!plan || B <= 0 || Lw <= plan->p.n_fft / 2) return 0;
-  const size_t T = 1 + Lw / plan->p.hop_length;
+  const size_t T = (size_t)stft_frames(plan, Lw);
   if (plan->generic)  // magnitudes [B*T][fs] + frame-major mel amplitudes [B*T][Mpad]
     return align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256) + align_up((size_t)B * T * plan->Mpad * sizeof(float), 256);
   // the fused kernel keeps the magnitudes on chip: its scratch is the frame-major copy of the mel amplitudes
@@ -825,7 +862,7 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
   RFX_ON_DEVICE(plan->device);
   if (plan->generic) {
     if (!plan->fwd_ok) return fail(RFX_ERR_UNSUPPORTED, "rfx_mel_from_waveform: filterbank is not banded: " + plan->imel_why);
-    const int T = 1 + Lw / plan->gg.hop;
+    const int T = stft_frames(plan, Lw);
     float* mag = (float*)d_workspace;
     float* mel_tm = (float*)((char*)d_workspace + align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256));
     int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);

@@ -44,6 +44,15 @@ class RfxParams(ctypes.Structure):
     ]
 
 
+class RfxPlanOptions(ctypes.Structure):
+    """rfx_plan_options of include/rfx.h."""
+
+    _fields_ = [("struct_size", ctypes.c_uint32), ("gl_form", ctypes.c_int32), ("gl_frames_per_slot", ctypes.c_int32)]
+
+
+GL_FORMS = {"auto": 0, "runs": 1, "frames": 2}  # rfx_gl_form
+
+
 class RfxError(RuntimeError):
     pass
 
@@ -58,6 +67,9 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_plan_is_generic": (c_int, [c_void_p]),
     "rfx_mel_scale_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_plan_create": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
+    "rfx_plan_create_ex": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "rfx_griffinlim_form": (c_int, [c_void_p, c_int, c_int]),
+    "rfx_stft_frames": (c_int, [c_void_p, c_int]),
     "rfx_plan_destroy": (c_int, [c_void_p]),
     "rfx_pack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rfx_pack_complex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -188,8 +200,11 @@ def mel_filterbank(
 class Plan:
     """Owns one rfx_plan (device constants for one parameter set on one device)."""
 
-    def __init__(self, params: T.Any, device: torch.device):
+    def __init__(self, params: T.Any, device: torch.device, gl_form: str = "auto"):
         self.lib = load_library()
+        if gl_form not in GL_FORMS:
+            raise ValueError(f"gl_form must be one of {sorted(GL_FORMS)}, got {gl_form!r}")
+        self.gl_form = gl_form
         self.device = device
         self.n_fft, self.win_length, self.hop_length = params.n_fft, params.win_length, params.hop_length
         self.n_stft = self.n_fft // 2 + 1
@@ -207,9 +222,10 @@ class Plan:
         cp = RfxParams(params.sample_rate, self.n_fft, self.win_length, self.hop_length, self.n_mels, params.max_mel_iters)
         handle = c_void_p()
         self.device = device = resolve_device(device)
+        opt = RfxPlanOptions(ctypes.sizeof(RfxPlanOptions), GL_FORMS[gl_form], 0)
         check(
-            self.lib.rfx_plan_create(
-                ctypes.byref(cp), self.window.data_ptr(), self.melfb.data_ptr(), device.index, ctypes.byref(handle)
+            self.lib.rfx_plan_create_ex(
+                ctypes.byref(cp), self.window.data_ptr(), self.melfb.data_ptr(), device.index, ctypes.byref(opt), ctypes.byref(handle)
             )
         )
         self.handle = handle
@@ -264,7 +280,7 @@ class Plan:
                 f"Argument #4: Padding size should be less than the corresponding input dimension, "
                 f"but got: padding ({self.n_fft // 2}, {self.n_fft // 2}) at dimension 2 of input {list(wave.shape)}"
             )
-        Tn = 1 + Lw // self.hop_length
+        Tn = self.lib.rfx_stft_frames(self.handle, Lw)  # torch.stft's count: 1 + (Lw + 2*(n_fft//2) - n_fft) // hop
         mag = torch.empty((B * Tn, self.frame_stride), dtype=torch.float32, device=wave.device) if want_mag else None
         spec = torch.empty((B * Tn, self.frame_stride), dtype=torch.complex64, device=wave.device) if want_spec else None
         check(
@@ -356,7 +372,7 @@ class Plan:
                 f"Argument #4: Padding size should be less than the corresponding input dimension, "
                 f"but got: padding ({self.n_fft // 2}, {self.n_fft // 2}) at dimension 2 of input {list(wave.shape)}"
             )
-        Tn = 1 + Lw // self.hop_length
+        Tn = self.lib.rfx_stft_frames(self.handle, Lw)
         need = self.lib.rfx_mel_workspace_bytes(self.handle, B, Lw)
         ws = torch.empty(need, dtype=torch.uint8, device=wave.device)
         out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=wave.device)
@@ -460,18 +476,21 @@ class Plan:
         return pcm, peak
 
 
-_plans: T.Dict[T.Tuple[T.Any, int], Plan] = {}
+_plans: T.Dict[T.Tuple[T.Any, int, str], Plan] = {}
 _plans_lock = threading.Lock()
 
 
-def get_plan(params: T.Any, device: T.Union[str, torch.device]) -> Plan:
-    """Plans are immutable and cached per (frozen params, device): constructing a converter per
-    request, as the reference's server does (server.py:159), costs a dictionary lookup."""
+def get_plan(params: T.Any, device: T.Union[str, torch.device], gl_form: str = "auto") -> Plan:
+    """Plans are immutable and cached per (frozen params, device, options): constructing a converter per
+    request, as the reference's server does (server.py:159), costs a dictionary lookup.
+
+    `gl_form` picks the Griffin-Lim device form (rfx_plan_options.gl_form): "auto" (per call, from the batch
+    shape), "runs" (always the run-based fused kernel) or "frames" (always the per-frame kernel + fold)."""
     dev = resolve_device(device)  # 'cuda' is keyed by the GPU it means now, not bound for good to the first one used
-    key = (params, dev.index)
+    key = (params, dev.index, gl_form)
     with _plans_lock:
         plan = _plans.get(key)
         if plan is None:
-            plan = Plan(params, dev)
+            plan = Plan(params, dev, gl_form)
             _plans[key] = plan
     return plan

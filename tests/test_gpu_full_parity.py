@@ -70,12 +70,12 @@ def test_mono_tile_full_size_inverse_mel_and_griffinlim32(O):
     want = O.griffinlim(want_lin, op, angles0=angles0, n_iter=32)
     want4 = O.griffinlim(want_lin, op, angles0=angles0, n_iter=4)
     # both device forms of Griffin-Lim: a single tile takes the small-batch kernels by default; the run-based kernel of the
-    # headline batch is forced through a plan created under RFX_GL_LATENCY_MODE=0
-    os.environ["RFX_GL_LATENCY_MODE"] = "0"
-    try:
-        plan_runs = _plan(SpectrogramParams(max_mel_iters=197))
-    finally:
-        os.environ.pop("RFX_GL_LATENCY_MODE")
+    # headline batch is asked for at plan creation (rfx_plan_options.gl_form)
+    from riffusion import _hip
+
+    plan_runs = _hip.get_plan(params, "cuda", gl_form="runs")
+    assert plan.lib.rfx_griffinlim_form(plan.handle, 1, T_FULL) == _hip.GL_FORMS["frames"]
+    assert plan.lib.rfx_griffinlim_form(plan.handle, 64, T_FULL) == _hip.GL_FORMS["runs"]
     for name, pl in (("small-batch kernels", plan), ("run-based kernel", plan_runs)):
         slots = pl.pack_magnitudes(want_lin.cuda())
         a0 = pl.pack_complex(angles0.cuda())

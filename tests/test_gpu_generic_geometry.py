@@ -209,6 +209,34 @@ def test_other_parameter_sets_end_to_end(O, kw):
     assert got.shape == want.shape and s >= 80.0
 
 
+@pytest.mark.parametrize("extra", [0, 1, 2])
+def test_odd_n_fft_frame_count_is_torch_stft_s(O, extra):
+    """torch.stft(center=True) pads n_fft//2 on both sides: 1 + (Lw + 2*(n_fft//2) - n_fft)//hop frames, which for ODD n_fft is
+    1 + (Lw-1)//hop - one frame fewer than 1 + Lw//hop exactly when Lw is a multiple of the hop (extra = 0)."""
+    p = _params(sample_rate=34650, padded_duration_ms=100, window_duration_ms=100, max_frequency=8000)  # n_fft 3465, hop 346
+    assert p.n_fft % 2 == 1
+    op = O.params_from(p)
+    plan = _plan(p)
+    Lw = p.hop_length * 30 + extra
+    wave = synthetic_wave(2, Lw, seed=extra)
+    ref = O.stft_complex(wave, op)
+    want_T = 1 + (Lw + 2 * (p.n_fft // 2) - p.n_fft) // p.hop_length
+    assert ref.shape[-1] == want_T == (30 if extra == 0 else 31)
+    assert plan.lib.rfx_stft_frames(plan.handle, Lw) == want_T
+    _, spec, Tn = plan.stft(wave.cuda(), want_mag=False, want_spec=True)
+    got = plan.unpack_complex(spec, 2, Tn).cpu()
+    assert Tn == want_T and got.shape == ref.shape
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 3e-6
+    mel_ref = O.mel_amplitudes_from_waveform(wave, op)
+    mel = plan.mel_from_waveform(wave.cuda()).cpu()
+    assert mel.shape == mel_ref.shape and torch.linalg.norm(mel - mel_ref) / torch.linalg.norm(mel_ref) <= 1e-4
+    # even n_fft: the count is 1 + Lw//hop, also at multiples of the hop
+    pe = _params(sample_rate=48000)
+    ple = _plan(pe)
+    assert ple.lib.rfx_stft_frames(ple.handle, pe.hop_length * 30) == 31
+    assert ple.lib.rfx_stft_frames(ple.handle, pe.n_fft // 2) == 0  # too short for the reflect padding: the reference raises
+
+
 def test_full_size_round_trip_at_48k():
     """512-frame clips at 48 kHz: ISTFT(STFT(x)) = x through the generic engine (n_iter = 0 with the true phases)."""
     p = _params(sample_rate=48000)

@@ -11,24 +11,17 @@ from helpers import snr_db, synthetic_wave
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["small-batch kernels", "run-based kernel"])
+@pytest.fixture(scope="module", params=["frames", "runs"])
 def plan(request):
     """Griffin-Lim has two device forms (csrc/rfx_gl.hip): small batches (<= 4 frames per resident workgroup slot, i.e. most
     shapes in this file) take gl_frame_kernel + gl_fold_kernel, larger ones the run-based gl_iter_kernel of the headline.
-    RFX_GL_LATENCY_MODE=0 (read at plan creation) forces the run-based kernel, so every test below runs on both."""
-    import os
-
+    The form is a plan-creation option (rfx_plan_options.gl_form, include/rfx.h), so every test below runs on both."""
     from riffusion import _hip
     from riffusion.spectrogram_params import SpectrogramParams
 
-    if request.param == "small-batch kernels":
-        return _hip.get_plan(SpectrogramParams(), "cuda")
-    old = os.environ.get("RFX_GL_LATENCY_MODE")
-    os.environ["RFX_GL_LATENCY_MODE"] = "0"
-    try:
-        return _hip.get_plan(SpectrogramParams(max_mel_iters=197), "cuda")  # another cache key -> a plan created under the override
-    finally:
-        os.environ.pop("RFX_GL_LATENCY_MODE") if old is None else os.environ.__setitem__("RFX_GL_LATENCY_MODE", old)
+    pl = _hip.get_plan(SpectrogramParams(), "cuda", gl_form=request.param)
+    assert pl.lib.rfx_griffinlim_form(pl.handle, 1, 48) == _hip.GL_FORMS[request.param]
+    return pl
 
 
 @pytest.fixture(scope="module")
