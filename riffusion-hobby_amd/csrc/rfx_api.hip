@@ -152,6 +152,11 @@ int rfx_num_bins(void) { return kBins; }
 int rfx_plan_frame_stride(const rfx_plan* plan) { return plan ? plan->frame_stride : 0; }
 int rfx_plan_is_generic(const rfx_plan* plan) { return plan && plan->generic ? 1 : 0; }
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
+int rfx_plan_imel_kernel(const rfx_plan* plan) {
+  if (!plan || !plan->d_melfb || !plan->imel_ok) return -1;
+  if (plan->imel_variant == 2) return 0;
+  return plan->imel.fast_ok >= 2 && plan->imel_variant != 1 ? 2 : plan->imel.fast_ok >= 1 ? 1 : 0;
+}
 // torch.stft(center=True): the signal is reflect-padded by n_fft/2 on both sides, so a waveform of Lw samples gives
 // 1 + (Lw + 2*(n_fft/2) - n_fft) / hop frames: 1 + Lw/hop for even n_fft, 1 + (Lw - 1)/hop for odd n_fft
 static int stft_frames(const rfx_plan* plan, int Lw) {

@@ -139,12 +139,25 @@ def test_filterbank_matches_oracle_bitwise():
     import riffusion_oracle as O
     from riffusion import _hip
 
-    for kw in ({}, {"min_frequency": 20, "max_frequency": 20000}, {"num_frequencies": 256}):
+    for kw in ({}, {"min_frequency": 20, "max_frequency": 20000}, {"num_frequencies": 256},
+               # the two mel parameters the reference exposes besides the defaults (spectrogram_params.py:34-35)
+               {"mel_scale_type": "slaney"}, {"mel_scale_norm": "slaney"}, {"mel_scale_type": "slaney", "mel_scale_norm": "slaney"},
+               {"mel_scale_type": "slaney", "sample_rate": 48000, "max_frequency": 16000}):
         p = SpectrogramParams(**kw)
         fb = _hip.mel_filterbank(p.n_fft // 2 + 1, float(p.min_frequency), float(p.max_frequency), p.num_frequencies,
                                  p.sample_rate, p.mel_scale_norm, p.mel_scale_type)
         assert torch.equal(fb, O.mel_filterbank(O.params_from(p)))
     assert torch.equal(_hip.hann_window(4410), O.hann_window(O.OracleParams()))
+    # slaney normalisation rescales the columns of the HTK bank without touching its sparsity pattern (same SGD kernel);
+    # the slaney scale moves the filter edges (linear below 1 kHz, logarithmic above)
+    htk = _hip.mel_filterbank(8821, 0.0, 10000.0, 512, 44100, None, "htk")
+    htk_n = _hip.mel_filterbank(8821, 0.0, 10000.0, 512, 44100, "slaney", "htk")
+    sl = _hip.mel_filterbank(8821, 0.0, 10000.0, 512, 44100, None, "slaney")
+    assert torch.equal(htk != 0, htk_n != 0) and not torch.equal(htk != 0, sl != 0)
+    assert float(htk.max()) <= 1.0 and float(htk_n.max()) < 0.5
+    for bad in ({"norm": "l2", "mel_scale": "htk"}, {"norm": None, "mel_scale": "bark"}):
+        with pytest.raises(ValueError):
+            _hip.mel_filterbank(8821, 0.0, 10000.0, 512, 44100, bad["norm"], bad["mel_scale"])
 
 
 # ---- C ABI surface ------------------------------------------------------------------------------------------------
