@@ -153,9 +153,10 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
  * channels and frames).  d_spec0: optional injected start (B, T, n_stft) float32 in the reference's
  * own layout, NULL = U[0,1) from `seed`.  Output: linear magnitudes in slot layout, ready for
  * rfx_griffinlim. */
-/* which SGD kernel rfx_inverse_mel runs for this plan's filterbank: 2 = group kernel with per-wave register budgets (the
- * default 512-filter HTK bank, with or without slaney normalisation), 1 = group kernel with a uniform budget (banks whose
- * groups fit 8 / 24 bins), 0 = general LDS kernel (any banded bank, e.g. mel_scale_type "slaney"), -1 = not banded */
+/* which SGD kernel rfx_inverse_mel runs for this plan's filterbank: 2 = group kernel with per-wave register budgets sized to
+ * the default 512-filter HTK bank (with or without slaney normalisation), 3 = the same kernel with the wider budget set
+ * (mel_scale_type "slaney"), 1 = group kernel with a uniform budget (other banks whose groups fit 8 / 24 bins),
+ * 0 = general LDS kernel (any banded bank), -1 = not banded (rfx_inverse_mel refuses) */
 int rfx_plan_imel_kernel(const rfx_plan* plan);
 size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T);
 int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,

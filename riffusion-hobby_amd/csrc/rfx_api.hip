@@ -113,6 +113,9 @@ struct rfx_plan {
   int* d_band_lo = nullptr;        // [Mpad] followed by band_len [Mpad]
   int band_rows = 0, Mpad = 0;
   bool fwd_unfused = false;        // debugging override (RFX_FWD_UNFUSED), read once at creation
+  float* d_slot_w = nullptr;       // product form of the fused kernel: [2][21][kQPad] per-slot weights (w0 then w1) ...
+  int* d_slot_idx = nullptr;       // ... [21][kQPad] bin positions followed by [3][Mpad] filter ranges; null: table form
+  unsigned fwd_kb_mask = 0;
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
   bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
   int gl_latency_frames_per_slot = 4;  // ... up to this many frames per resident workgroup slot (RFX_GL_LATENCY_FRAMES)
@@ -155,7 +158,8 @@ int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
 int rfx_plan_imel_kernel(const rfx_plan* plan) {
   if (!plan || !plan->d_melfb || !plan->imel_ok) return -1;
   if (plan->imel_variant == 2) return 0;
-  return plan->imel.fast_ok >= 2 && plan->imel_variant != 1 ? 2 : plan->imel.fast_ok >= 1 ? 1 : 0;
+  if (plan->imel_variant == 1) return plan->imel.fast_ok == 1 || plan->imel.fast_ok == 2 ? 1 : 0;
+  return plan->imel.fast_ok;
 }
 // torch.stft(center=True): the signal is reflect-padded by n_fft/2 on both sides, so a waveform of Lw samples gives
 // 1 + (Lw + 2*(n_fft/2) - n_fft) / hop frames: 1 + Lw/hop for even n_fft, 1 + (Lw - 1)/hop for odd n_fft
@@ -383,7 +387,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     // group formulation (fast kernel): active bins contiguous with no zero row inside, first-filter index
     // non-decreasing, and the per-thread pairing (short group t, long group M-1-t) fits 8 + 24 registers
     std::vector<int> grp_start(M + 1, 0);
-    bool fast = ok && M <= 512, perwave = false;
+    bool fast = ok && M <= 512;
+    int fast_code = 0;
     if (fast) {
       int prev = 0;
       for (int f = f_lo; f < f_hi && fast; ++f) {
@@ -396,21 +401,20 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
         int acc = f_lo;
         for (int g2 = 0; g2 < M; ++g2) { grp_start[g2] = acc; acc += cnt[g2]; }
         grp_start[M] = acc;
-        for (int t2 = 0; t2 < 256 && fast; ++t2) {
-          const int gH = M - 1 - t2, gL = t2 < M - 256 ? t2 : -1;
-          if (gH >= 0 && cnt[gH] > 24) fast = false;
-          if (gL >= 0 && cnt[gL] > 8) fast = false;
-          if (gL >= 0 && gH >= 0 && gL >= gH) fast = false;
-        }
-        // per-wave register budgets of imel_group_kernel_perwave (rfx_kernels.h)
-        const int* lo_cap = rfx::kImelLoCap;
-        const int* hi_cap = rfx::kImelHiCap;
-        perwave = fast;
-        for (int t2 = 0; t2 < 256 && perwave; ++t2) {
-          const int gH = M - 1 - t2, gL = t2 < M - 256 ? t2 : -1;
-          if (gH >= 0 && cnt[gH] > hi_cap[t2 >> 6]) perwave = false;
-          if (gL >= 0 && cnt[gL] > lo_cap[t2 >> 6]) perwave = false;
-        }
+        // which register budgets the bank's groups fit: thread role t2 owns the long group M-1-t2 and the short group t2
+        auto fits = [&](const int* lo_cap, const int* hi_cap) {
+          for (int t2 = 0; t2 < 256; ++t2) {
+            const int gH = M - 1 - t2, gL = t2 < M - 256 ? t2 : -1;
+            if (gH >= 0 && cnt[gH] > hi_cap[t2 >> 6]) return false;
+            if (gL >= 0 && cnt[gL] > lo_cap[t2 >> 6]) return false;
+            if (gL >= 0 && gH >= 0 && gL >= gH) return false;
+          }
+          return true;
+        };
+        const int uni_lo[4] = {8, 8, 8, 8}, uni_hi[4] = {24, 24, 24, 24};
+        // per-wave budgets of imel_group_kernel_perwave (rfx_kernels.h): the default bank's exact set, then the wide set
+        fast_code = fits(rfx::kImelLoCap, rfx::kImelHiCap) ? 2 : fits(rfx::kImelLoCapWide, rfx::kImelHiCapWide) ? 3 : fits(uni_lo, uni_hi) ? 1 : 0;
+        fast = fast_code != 0;
       }
     }
     pl->imel_ok = ok;
@@ -446,6 +450,55 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->band_rows = rows;
       pl->Mpad = Mpad;
       pl->fwd_ok = true;
+      // product form of the fused kernel (stft_mel2_kernel): per-slot weights / bin positions and per-filter ranges.
+      // Needs the first-filter index to be non-decreasing over the active bins, so that a filter's band is its rising
+      // part (bins whose SECOND filter it is) followed by its falling part (bins whose FIRST filter it is).
+      if (!generic && M <= 2 * kThreads && getenv("RFX_FWD_V1") == nullptr) {
+        const int nb = f_hi - f_lo;
+        std::vector<int> rng(3 * (size_t)Mpad, 0);
+        bool v2 = 2 * nb <= 2 * kCubeElems;
+        for (int m = 0; m < M && v2; ++m) {
+          const int lo = band_lo[m], hi = band_hi[m];
+          int mid = hi;
+          for (int f = lo; f < hi; ++f)
+            if (bin_m0[f] == m) { mid = f; break; }
+          for (int f = lo; f < hi && v2; ++f) {
+            const float want = h_melfb[(size_t)f * M + m];
+            if (f < mid) v2 = bin_m0[f] == m - 1 && bin_w1[f] == want;
+            else v2 = bin_m0[f] == m && bin_w0[f] == want;
+          }
+          rng[m] = lo - f_lo;
+          rng[Mpad + m] = mid - f_lo;
+          rng[2 * (size_t)Mpad + m] = hi - f_lo;
+        }
+        if (v2) {
+          std::vector<float> sw0(21 * (size_t)kQPad, 0.f), sw1(21 * (size_t)kQPad, 0.f);
+          std::vector<int> sidx(21 * (size_t)kQPad, -1);
+          std::vector<char> seen(F, 0);
+          unsigned mask = 0;
+          for (int k1 = 0; k1 < 21; ++k1)
+            for (int ka = 0; ka < 21; ++ka)
+              for (int kb = 0; kb < 21; ++kb) {
+                bool cj;
+                const int bin = slot_bin(k1, ka, kb, &cj);
+                if (seen[bin]) continue;  // the duplicate slot of a bin contributes nothing
+                seen[bin] = 1;
+                if (bin < f_lo || bin >= f_hi || bin_m0[bin] < 0) continue;
+                const size_t o = (size_t)kb * kQPad + slot_qp(k1 * 21 + ka);
+                sw0[o] = bin_w0[bin];
+                sw1[o] = bin_w1[bin];
+                sidx[o] = bin - f_lo;
+                mask |= 1u << kb;
+              }
+          RFX_HIP(hipMalloc(&pl->d_slot_w, 2 * sw0.size() * sizeof(float)));
+          RFX_HIP(hipMemcpy(pl->d_slot_w, sw0.data(), sw0.size() * sizeof(float), hipMemcpyHostToDevice));
+          RFX_HIP(hipMemcpy(pl->d_slot_w + sw0.size(), sw1.data(), sw1.size() * sizeof(float), hipMemcpyHostToDevice));
+          RFX_HIP(hipMalloc(&pl->d_slot_idx, (sidx.size() + rng.size()) * sizeof(int)));
+          RFX_HIP(hipMemcpy(pl->d_slot_idx, sidx.data(), sidx.size() * sizeof(int), hipMemcpyHostToDevice));
+          RFX_HIP(hipMemcpy(pl->d_slot_idx + sidx.size(), rng.data(), rng.size() * sizeof(int), hipMemcpyHostToDevice));
+          pl->fwd_kb_mask = mask;
+        }
+      }
       pl->fwd_unfused = getenv("RFX_FWD_UNFUSED") != nullptr;
     }
     if (ok) {
@@ -478,7 +531,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->imel.bin_pos = (const int*)(d + o_p);
       pl->imel.bin_pos2 = (const int*)(d + o_p2);
       pl->imel.grp_start = (const int*)(d + o_gs);
-      pl->imel.fast_ok = fast ? (perwave ? 2 : 1) : 0;
+      pl->imel.fast_ok = fast ? fast_code : 0;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;
@@ -503,6 +556,8 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_band_wt);
     (void)hipFree(plan->d_band_lo);
     (void)hipFree(plan->d_band_addr);
+    (void)hipFree(plan->d_slot_w);
+    (void)hipFree(plan->d_slot_idx);
     (void)hipFree(plan->d_gen_tables);
     (void)hipFree(plan->d_gen_rev);
   }
@@ -896,9 +951,17 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     f.Mpad = plan->Mpad;
     f.f_lo = plan->imel.f_lo;
     f.f_hi = plan->imel.f_hi;
+    f.slot_w0 = plan->d_slot_w;
+    f.slot_w1 = plan->d_slot_w ? plan->d_slot_w + 21 * (size_t)kQPad : nullptr;
+    f.slot_idx = plan->d_slot_idx;
+    f.filt_rng = plan->d_slot_idx ? plan->d_slot_idx + 21 * (size_t)kQPad : nullptr;
+    f.kb_mask = plan->fwd_kb_mask;
+    // runs of consecutive frames: every resident workgroup slot of the chip gets one run when the batch allows it (the
+    // product-form kernel carries a sliding input window along a run), at most 64 frames, at least 1
     const long long frames = (long long)B * f.T;
+    const int cap = plan->d_slot_w ? 64 : 16;
     int fpb = (int)((frames + 2LL * plan->num_cus - 1) / (2LL * plan->num_cus));
-    f.frames_per_block = fpb < 1 ? 1 : fpb > 16 ? 16 : fpb;
+    f.frames_per_block = fpb < 1 ? 1 : fpb > cap ? cap : fpb;
     RFX_HIP(launch_stft_mel(f, (hipStream_t)stream));
     return RFX_OK;
   }

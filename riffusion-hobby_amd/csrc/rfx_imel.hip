@@ -188,16 +188,33 @@ __device__ __forceinline__ float dpp_add(float x) {
   const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true);
   return x + __builtin_bit_cast(float, y);
 }
-// sum over the 64 lanes of a wave (result valid in every lane): 4 DPP adds inside rows of 16 + 4 readlanes
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_rows(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false);
+  return x + __builtin_bit_cast(float, y);
+}
+// sum over the 64 lanes of a wave (wave-uniform result): 4 DPP adds inside the rows of 16, then the row sums travel up
+// through lane 15 (row_bcast:15 into rows 1 and 3) and lane 31 (row_bcast:31 into rows 2 and 3); lane 63 holds the total
 __device__ __forceinline__ float wave_sum(float x) {
   x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
   x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
   x = dpp_add<0x141>(x);  // row_half_mirror
   x = dpp_add<0x140>(x);  // row_mirror
+#ifndef RFX_IMEL_READLANE_SUM
+  x = dpp_add_rows<0x142, 0xA>(x);  // row_bcast:15
+  x = dpp_add_rows<0x143, 0xC>(x);  // row_bcast:31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+#else
   const int xi = __builtin_bit_cast(int, x);
   return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16))) +
          (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48)));
+#endif
 }
+
+// LDS of one frame of the group formulation: A and B double-buffered ([2][M + 4] each: entry m at index m + 1, zero pads
+// at m = -1 and m = M, a dump entry for absent groups at m = M + 1 and its right neighbour), per-wave partial losses
+// [max_iter][4]
+RFX_HD size_t imel_group_lds_bytes(int M, int max_iter) { return sizeof(float) * (size_t)(4 * (M + 4) + 4 * max_iter); }
 
 template <int N>
 struct GroupState {
@@ -236,12 +253,13 @@ __device__ __forceinline__ void group_ab(const GroupState<N>& g, float& A, float
   B = b0 + b1;
 }
 template <int N>
-__device__ __forceinline__ void group_step(GroupState<N>& g, float d0, float d1, bool first, float mom, float lr) {
+__device__ __forceinline__ void group_step(GroupState<N>& g, float d0, float d1, float mom, float lr) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     // torch.optim.SGD: buf.mul_(momentum).add_(grad); accumulating in place keeps buf in its register
-    // (a separate gradient temporary costs a v_mov per bin and step across the loop back-edge)
-    float bnew = first ? 0.f : mom * g.buf[i];
+    // (a separate gradient temporary costs a v_mov per bin and step across the loop back-edge).  The first step's
+    // buf = grad needs no special case: buf starts at +0 and momentum * 0 is +0
+    float bnew = mom * g.buf[i];
     bnew = fmaf(d0, g.w0[i], bnew);
     bnew = fmaf(d1, g.w1[i], bnew);
     g.buf[i] = bnew;
@@ -260,21 +278,22 @@ __device__ __forceinline__ void group_store(const GroupState<N>& g, const ImelTa
     }
 }
 
+// `tid` is the thread's ROLE (0..255: which two groups it owns; roles 64c..64c+63 form size class c), not its hardware
+// index: the kernels below deal the four classes to the waves of a workgroup in different orders.  `frame` is the frame
+// this wave's workgroup slot works on, `live` false for a slot past the last frame (it runs the same barriers on a copy of
+// the last frame's data and stores nothing).
 template <int NLO, int NHI>
-__device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem) {
+__device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, int tid, int frame, bool live) {
   const ImelTables& tb = a.tb;
   const int M = a.M;
-  float* Ab = reinterpret_cast<float*>(smem);  // [2][M + 2], entry m at index m + 1
-  float* Bb = Ab + 2 * (M + 2);                // [2][M + 2]
-  float* red = Bb + 2 * (M + 2);               // [2][4]
-  float* hist_s = red + 8;                     // [max_iter]
+  float* Ab = reinterpret_cast<float*>(smem);  // [2][M + 4], entry m at index m + 1
+  float* Bb = Ab + 2 * (M + 4);                // [2][M + 4]
+  float* part = Bb + 2 * (M + 4);              // [max_iter][4] per-wave partial sums of diff^2
 
-  const int frame = blockIdx.x;
   const int b = frame / a.T, t = frame - b * a.T;
   const int clip = b / a.C;
-  const int tid = threadIdx.x;
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
-  if (a.it_limit && steps >= a.max_iter) return;
+  if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass (one frame per workgroup): this clip never stopped early
   const unsigned long long rbase = (unsigned long long)frame * a.n_stft;
 
   const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;           // long groups, counted down from the top
@@ -286,39 +305,45 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem) {
   auto melat = [&](int m) { return (m >= 0 && m < M) ? a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
   const float mL0 = gL >= 0 ? melat(gL) : 0.f, mL1 = gL >= 0 ? melat(gL + 1) : 0.f;
   const float mH0 = gH >= 0 ? melat(gH) : 0.f, mH1 = gH >= 0 ? melat(gH + 1) : 0.f;
-  for (int i = tid; i < 4 * (M + 2); i += kImelThreads) Ab[i] = 0.f;  // Ab and Bb are contiguous: zero both incl. pads
+  for (int i = tid; i < 4 * (M + 4); i += kImelThreads) Ab[i] = 0.f;  // Ab and Bb are contiguous: zero both incl. pads
   const float gscale = -2.0f / (float)(a.C * a.T);
+  // an absent group (n_mels < 512) publishes zeros to the dump entry and reads the pads around it: the loop below has no
+  // branches, and the four neighbour reads of a step go out together (one LDS round trip, not four)
+  const int xL = (gL >= 0 ? gL : M + 1) + 1, xH = (gH >= 0 ? gH : M + 1) + 1;
+  const bool okL = gL >= 0, okH = gH >= 0;
+  const int wave = tid >> 6;
   __syncthreads();
 
-  for (int it = 0; it < steps; ++it) {
-    const int par = it & 1;
+  // one SGD step; Ap / Bp = this step's half of the double buffers (the parity is a compile-time matter of the caller)
+  auto sgd_step = [&](int it, float* __restrict__ Ap, float* __restrict__ Bp) {
     float AL, BL, AH, BH;
     group_ab(lo, AL, BL);
     group_ab(hi, AH, BH);
-    float* Ap = Ab + par * (M + 2) + 1;
-    float* Bp = Bb + par * (M + 2) + 1;
-    if (gL >= 0) { Ap[gL] = AL; Bp[gL] = BL; }
-    if (gH >= 0) { Ap[gH] = AH; Bp[gH] = BH; }
+    Ap[xL] = AL; Bp[xL] = BL;
+    Ap[xH] = AH; Bp[xH] = BH;
     __syncthreads();
-    if (tid == 0 && it > 0) hist_s[it - 1] = (red[(par ^ 1) * 4 + 0] + red[(par ^ 1) * 4 + 1]) + (red[(par ^ 1) * 4 + 2] + red[(par ^ 1) * 4 + 3]);
+    const float bLm = Bp[xL - 1], aLp = Ap[xL + 1], bHm = Bp[xH - 1], aHp = Ap[xH + 1];
     // residuals of the two filters each group feeds: d0 = diff[g], d1 = diff[g+1]
-    const float dL0 = gL >= 0 ? mL0 - AL - Bp[gL - 1] : 0.f;
-    const float dL1 = gL >= 0 ? mL1 - Ap[gL + 1] - BL : 0.f;
-    const float dH0 = gH >= 0 ? mH0 - AH - Bp[gH - 1] : 0.f;
-    const float dH1 = gH >= 0 ? mH1 - Ap[gH + 1] - BH : 0.f;
+    const float dL0 = okL ? mL0 - AL - bLm : 0.f;
+    const float dL1 = okL ? mL1 - aLp - BL : 0.f;
+    const float dH0 = okH ? mH0 - AH - bHm : 0.f;
+    const float dH1 = okH ? mH1 - aHp - BH : 0.f;
     const float sq = wave_sum(fmaf(dL0, dL0, dH0 * dH0));  // every filter's residual is owned exactly once
-    if ((tid & 63) == 0) red[par * 4 + (tid >> 6)] = sq;
+    if ((tid & 63) == 0) part[4 * it + wave] = sq;
     // the last filter has no successor: its d1 multiplies w1 == 0
-    group_step(lo, gscale * dL0, gscale * dL1, it == 0, a.momentum, a.lr);
-    group_step(hi, gscale * dH0, gscale * dH1, it == 0, a.momentum, a.lr);
+    group_step(lo, gscale * dL0, gscale * dL1, a.momentum, a.lr);
+    group_step(hi, gscale * dH0, gscale * dH1, a.momentum, a.lr);
+  };
+  float* const A0 = Ab, * const A1 = Ab + (M + 4), * const B0 = Bb, * const B1 = Bb + (M + 4);
+  int it = 0;
+  for (; it + 1 < steps; it += 2) {
+    sgd_step(it, A0, B0);
+    sgd_step(it + 1, A1, B1);
   }
-  __syncthreads();
-  if (tid == 0 && steps > 0) {
-    const int par = (steps - 1) & 1;
-    hist_s[steps - 1] = (red[par * 4 + 0] + red[par * 4 + 1]) + (red[par * 4 + 2] + red[par * 4 + 3]);
-  }
+  if (it < steps) sgd_step(it, A0, B0);
   __syncthreads();
 
+  if (!live) return;
   float* out = a.out_slots + (size_t)frame * a.out_stride;
   group_store(lo, tb, out);
   group_store(hi, tb, out);
@@ -338,30 +363,49 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem) {
     }
   }
   if (a.loss_hist && !a.it_limit)
-    for (int i = tid; i < a.max_iter; i += kImelThreads) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? hist_s[i] : 0.f;
+    for (int i = tid; i < a.max_iter; i += kImelThreads)
+      a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]) : 0.f;
 }
 
 // uniform register budget for every wave
 template <int NLO, int NHI>
 __global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  imel_group_body<NLO, NHI>(a, smem);
+  imel_group_body<NLO, NHI>(a, smem, threadIdx.x, blockIdx.x, true);
 }
-// group sizes fall with the wave index (mel spacing is logarithmic): each wave runs the body compiled for
-// its own maximum, so the long-group wave no longer sets everybody's instruction count.  All four bodies
-// execute the same sequence of barriers.
-template <int L0, int H0, int L1, int H1, int L2, int H2, int L3, int H3>
+// Group sizes fall with the role index (mel spacing is logarithmic): roles 64c..64c+63 form size class c, and each wave
+// runs the body compiled for its class's maximum, so the long-group class no longer sets everybody's instruction count.
+// All bodies execute the same sequence of barriers.
+//
+// FPW frames per workgroup (4 FPW waves).  The waves of a workgroup land on the CU's four SIMDs round-robin
+// (profiles/r01_wave_placement_ubench.txt: wave i and wave i+4 share a SIMD), and a class-0 wave issues 25/15 of a class-3
+// wave's instructions per SGD step.  With one frame per workgroup, which SIMD gets the heavy wave is left to the order
+// workgroups happen to arrive in; with FPW = 2 or 4 the classes are dealt so that the waves sharing a SIMD carry different
+// classes (FPW = 2: c and 3-c, FPW = 4: a Latin square, every SIMD gets one wave of each class).
 #ifndef RFX_IMEL_WAVES_PER_EU
-#define RFX_IMEL_WAVES_PER_EU 4  // 128 VGPRs: 4 workgroups per CU (7.6 ms vs 8.6 ms at 3, measured)
+#define RFX_IMEL_WAVES_PER_EU 4  // 128 VGPRs: 16 waves per CU (7.6 ms vs 8.6 ms at 3, measured)
 #endif
-__global__ void __launch_bounds__(kImelThreads) __attribute__((amdgpu_waves_per_eu(RFX_IMEL_WAVES_PER_EU)))
+#ifndef RFX_IMEL_FPW
+#define RFX_IMEL_FPW 1
+#endif
+template <int FPW, int WPE, int L0, int H0, int L1, int H1, int L2, int H2, int L3, int H3>
+__global__ void __launch_bounds__(kImelThreads * FPW) __attribute__((amdgpu_waves_per_eu(WPE)))
 imel_group_kernel_perwave(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: imel_group_body<L0, H0>(a, smem); break;
-    case 1: imel_group_body<L1, H1>(a, smem); break;
-    case 2: imel_group_body<L2, H2>(a, smem); break;
-    default: imel_group_body<L3, H3>(a, smem); break;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slot = wave >> 2, w4 = wave & 3;
+  const int cls = FPW == 1 ? w4 : FPW == 2 ? (slot ? 3 - w4 : w4) : ((w4 + slot) & 3);
+  const int tid = cls * 64 + (threadIdx.x & 63);
+  const int nframes = a.B * a.T;
+  int frame = blockIdx.x * FPW + slot;
+  const bool live = frame < nframes;
+  if (!live) frame = nframes - 1;
+  char* my = smem + (size_t)slot * imel_group_lds_bytes(a.M, a.max_iter);
+  switch (cls) {
+    case 0: imel_group_body<L0, H0>(a, my, tid, frame, live); break;
+    case 1: imel_group_body<L1, H1>(a, my, tid, frame, live); break;
+    case 2: imel_group_body<L2, H2>(a, my, tid, frame, live); break;
+    default: imel_group_body<L3, H3>(a, my, tid, frame, live); break;
   }
 }
 
@@ -408,14 +452,29 @@ __global__ void __launch_bounds__(1024) imel_scan_kernel(const float* __restrict
   }
 }
 
+template <int FPW, int SET>
+static void launch_perwave(const ImelArgs& a, hipStream_t stream) {
+  const int nframes = a.B * a.T;
+  const size_t lds = FPW * imel_group_lds_bytes(a.M, a.max_iter);
+  constexpr const int* lo = SET == 0 ? kImelLoCap : kImelLoCapWide;
+  constexpr const int* hi = SET == 0 ? kImelHiCap : kImelHiCapWide;
+  // the wide set's class 0 holds 31 bins per thread (124 state registers): three waves per SIMD (168 VGPRs) instead of four
+  constexpr int wpe = SET == 0 ? RFX_IMEL_WAVES_PER_EU : 3;
+  hipLaunchKernelGGL((imel_group_kernel_perwave<FPW, wpe, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]>), dim3((nframes + FPW - 1) / FPW),
+                     dim3(kImelThreads * FPW), lds, stream, a);
+}
+
 hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
-  if (a.tb.fast_ok && variant != 2) {
-    const size_t lds = sizeof(float) * (4 * (a.M + 2) + 8 + a.max_iter);
-    if (a.tb.fast_ok >= 2 && variant != 1)
-      hipLaunchKernelGGL((imel_group_kernel_perwave<kImelLoCap[0], kImelHiCap[0], kImelLoCap[1], kImelHiCap[1], kImelLoCap[2], kImelHiCap[2],
-                                                   kImelLoCap[3], kImelHiCap[3]>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
-    else
-      hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
+  if (a.tb.fast_ok && variant != 2 && !(variant == 1 && a.tb.fast_ok == 3)) {  // (the wide set has no uniform fallback: general kernel)
+    // the fix-up pass runs a different number of steps (and barriers) per clip: one frame per workgroup there
+    const bool fixup = a.it_limit != nullptr;
+    if (a.tb.fast_ok == 2 && variant != 1) {
+      if (fixup) launch_perwave<1, 0>(a, stream); else launch_perwave<RFX_IMEL_FPW, 0>(a, stream);
+    } else if (a.tb.fast_ok == 3 && variant != 1) {
+      if (fixup) launch_perwave<1, 1>(a, stream); else launch_perwave<RFX_IMEL_FPW, 1>(a, stream);
+    } else {
+      hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), imel_group_lds_bytes(a.M, a.max_iter), stream, a);
+    }
     return hipGetLastError();
   }
   const int nb = a.tb.f_hi - a.tb.f_lo;

@@ -83,6 +83,13 @@ struct StftMelArgs {
   int B, T, Lw, frames_per_block;
   int M, Mpad;           // Mpad = M rounded up to 64
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
+  // product form (stft_mel2_kernel; valid when slot_w0 != nullptr): the thread that owns a bin's primary slot multiplies
+  // |X| by the bin's two filterbank weights and scatters the products in BIN ORDER; a filter is then two contiguous sums
+  const float* slot_w0;  // [21][kQPad] weight of the slot's bin on its first filter (0: inactive bin / duplicate slot), kb-major
+  const float* slot_w1;  // [21][kQPad] weight on the next filter
+  const int* slot_idx;   // [21][kQPad] bin - f_lo of the slot's bin, or -1 when the slot contributes nothing
+  const int* filt_rng;   // [3][Mpad]: lo, mid, hi (relative to f_lo): filter m = sum prod1[lo..mid) + sum prod0[mid..hi)
+  unsigned kb_mask;      // bit kb set when any thread's slot kb contributes (wave-uniform skip of the other kb)
 };
 hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream);
 
@@ -103,6 +110,10 @@ hipError_t launch_mel_gemm(const MelArgs& a, hipStream_t stream);
 // does not fit.
 constexpr int kImelLoCap[4] = {2, 3, 5, 6};
 constexpr int kImelHiCap[4] = {23, 16, 12, 9};
+// a second set for banks whose edges sit elsewhere: mel_scale_type "slaney" (spectrogram_params.py:35; linear below 1 kHz,
+// so its low groups are longer, and its top groups reach 26 bins)
+constexpr int kImelLoCapWide[4] = {5, 3, 5, 6};
+constexpr int kImelHiCapWide[4] = {26, 17, 12, 9};
 
 // banded InverseMelScale SGD (torchaudio 0.13 semantics), one workgroup per frame
 struct ImelTables {
@@ -117,7 +128,8 @@ struct ImelTables {
   const int* grp_start;  // [M+1] first bin of group g (bins whose first filter is g), fast path only
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
   int nnz;
-  int fast_ok;           // 0: general kernel; 1: group formulation with <8, 24> bins per thread; 2: per-wave budgets fit too
+  int fast_ok;           // 0: general kernel; 1: group formulation with <8, 24> bins per thread; 2: per-wave budgets (default set) fit too;
+                         // 3: only the wide per-wave set fits
 };
 struct ImelArgs {
   ImelTables tb;

@@ -246,6 +246,139 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) { 
   }
 }
 
+// ---- fused forward path, product form.  What changed against stft_mel_kernel above, and why:
+//  * the transform half is the Griffin-Lim kernel's analysis half: a workgroup walks a RUN of consecutive frames, the ten
+//    input samples of thread n' are a register sliding window (one new load per frame, requested a frame ahead), the
+//    g(n')^k1 twiddles are requested during the mel phase of the previous frame (stft_mel_kernel fetched ten samples and
+//    twenty twiddles per frame and waited for them on the spot);
+//  * the mel phase reads no tables: the thread that owns a bin's primary slot holds |X| in a register anyway, multiplies it
+//    by the bin's (at most two) filterbank weights - frame-invariant, streamed from an L2-resident per-slot table under
+//    P2 / P3 like |S| in the Griffin-Lim kernel - and scatters the two products into bin-ordered LDS arrays prod0 / prod1
+//    (the cube is dead by then).  Filter m is then  sum prod1[lo..mid) + sum prod0[mid..hi): its rising part (bins whose
+//    SECOND filter it is) followed by its falling part (bins whose FIRST filter it is) - contiguous LDS reads, plain adds,
+//    still summed in increasing bin order.  stft_mel_kernel fetched a weight and an address per product from L2 in
+//    dependent steps of eight (7 976 x 2 loads per frame).
+// Cost: two more workgroup barriers per frame (all waves must have left P3 before the cube is overwritten with products).
+// KBMASK: the kb (of a thread's 21 slots) that can contribute, as a compile-time set: 0x1F001F (kb 0..4 and 16..20) covers
+// every bank that ends at or below bin 4200 (the default 0-10 kHz bank: bins 1..4000), 0x1FFFFF any bank.
+constexpr unsigned kKbMaskLow = 0x1F001Fu, kKbMaskAll = 0x1FFFFFu;
+#ifndef RFX_MEL_BATCH
+#define RFX_MEL_BATCH 16  // products fetched per LDS round trip in the filter sums
+#endif
+template <unsigned KBMASK>
+__global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ThreadId t = thread_id();
+  const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
+  const int nb = a.f_hi - a.f_lo;
+  float* prod = reinterpret_cast<float*>(smem);  // [0, nb): w0 * |X| in bin order; [nb, 2 nb): w1 * |X|
+
+  const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  const int clip = blockIdx.x / chunks;
+  const int f0 = (blockIdx.x - clip * chunks) * a.frames_per_block;
+  const int f1 = min(a.T, f0 + a.frames_per_block);
+  const rsrc_t xin = make_rsrc(a.wave + (size_t)clip * a.Lw, (size_t)a.Lw * 4);
+  const rsrc_t win = make_rsrc(a.win, kWin * 4);
+  const rsrc_t w0src = make_rsrc(a.slot_w0, 21 * kQPad * 4), w1src = make_rsrc(a.slot_w1, 21 * kQPad * 4);
+  const rsrc_t idsrc = make_rsrc(a.slot_idx, 21 * kQPad * 4);
+  const unsigned npr4 = (unsigned)t.npr * 4u;
+  const unsigned qp4 = (unsigned)slot_qp(t.npr) * 4u;
+
+  // the (up to two) filters of this thread: threadIdx and threadIdx + kThreads (the first wave carries the second
+  // filters: they are the LONGEST bands, its first filters the shortest).  A filter is the sum over [lo, hi) of
+  // prod[i + (i < mid ? nb : 0)]: rising part from the w1 products, falling part from the w0 products.
+  int lo[2], mid[2], hi[2];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const int m = threadIdx.x + w * kThreads;
+    const bool has = m < a.M;
+    lo[w] = has ? a.filt_rng[m] : 0;
+    mid[w] = has ? a.filt_rng[a.Mpad + m] : 0;
+    hi[w] = has ? a.filt_rng[2 * a.Mpad + m] : 0;
+  }
+
+  float w10[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w10[j] = ld1(win, npr4, (unsigned)j * (kHop * 4u));
+  auto load_x = [&](int blk) { return ld1(xin, (unsigned)reflect_index(blk * kHop + t.npr, a.Lw) * 4u, 0); };
+  float d[10];
+#pragma unroll
+  for (int j = 1; j < 10; ++j) d[j] = load_x(f0 + j - 1 - kHalfHops);
+  float d_next = load_x(f0 + 9 - kHalfHops);
+  Tw1 tw1;
+  load_tw1(tw1, f);
+  __syncthreads();  // tw2 table in LDS
+
+  for (int fr = f0; fr < f1; ++fr) {
+    float u[10];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) d[j] = d[j + 1];
+    d[9] = d_next;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) u[j] = d[j] * w10[j];
+    cf R[21];
+    float w0[21], w1[21];
+    int sidx[21];
+    frame_forward_tw(u, R, f, t, tw1,
+                     [&] { d_next = load_x(fr + 10 - kHalfHops); },  // after the analysis barrier: the next frame's new sample
+                     NoHook(),
+                     [&] {  // before P3 (P2's registers are free): the slots' weights and bin positions fly under P3
+#pragma unroll
+                       for (int kb = 0; kb < 21; ++kb)
+                         if ((KBMASK >> kb) & 1u) {
+                           w0[kb] = ld1(w0src, qp4, (unsigned)kb * (kQPad * 4u));
+                           w1[kb] = ld1(w1src, qp4, (unsigned)kb * (kQPad * 4u));
+                           sidx[kb] = __builtin_bit_cast(int, ld1(idsrc, qp4, (unsigned)kb * (kQPad * 4u)));
+                         }
+                     });
+#pragma unroll
+    for (int kb = 0; kb < 21; ++kb)
+      if ((KBMASK >> kb) & 1u) {
+        const float mag = sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
+        w0[kb] *= mag;
+        w1[kb] *= mag;
+      }
+    __syncthreads();  // every wave has left P3: the cube may be overwritten
+#ifndef RFX_NO_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if (t.active) {
+#pragma unroll
+      for (int kb = 0; kb < 21; ++kb)
+        if (((KBMASK >> kb) & 1u) && sidx[kb] >= 0) {
+          prod[sidx[kb]] = w0[kb];
+          prod[sidx[kb] + nb] = w1[kb];
+        }
+    }
+    load_tw1(tw1, f);  // for the next frame's P1: in flight across the mel phase
+    __syncthreads();
+    {
+      // frame-major scratch (Mpad contiguous floats per frame: whole-line stores); a tiled transpose brings it into the
+      // reference's (B, M, T) layout afterwards - 4-byte stores T floats apart cost 10x the bytes in HBM writes
+      float* __restrict__ row = a.mel_tm + ((size_t)clip * a.T + fr) * a.Mpad;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const int m = threadIdx.x + w * kThreads;
+        if (m >= a.Mpad) break;  // wave-uniform: only the first wave(s) carry a second filter
+        float s = 0.f;
+        const int last = hi[w] - 1;
+        for (int i = lo[w]; i < hi[w]; i += RFX_MEL_BATCH) {  // RFX_MEL_BATCH products per LDS round trip, summed in bin order
+          float v[RFX_MEL_BATCH];
+#pragma unroll
+          for (int j = 0; j < RFX_MEL_BATCH; ++j) {
+            const int q = min(i + j, last);
+            v[j] = prod[q + (q < mid[w] ? nb : 0)];
+          }
+#pragma unroll
+          for (int j = 0; j < RFX_MEL_BATCH; ++j) s += (i + j <= last) ? v[j] : 0.f;
+        }
+        row[m] = s;  // padding filters (m >= M): empty range, 0
+      }
+    }
+    __syncthreads();  // the next frame's P1 overwrites the products
+  }
+}
+
 // (B, T, Mpad) frame-major mel amplitudes -> the reference's (B, M, T): 64 x 64 tiles through LDS, both sides coalesced
 __global__ void __launch_bounds__(256) mel_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int M, int Mpad) {
   __shared__ float tile[64][65];
@@ -269,7 +402,11 @@ hipError_t launch_mel_transpose(const float* mel_tm, float* mel, int B, int T, i
 
 hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream) {
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
-  hipLaunchKernelGGL(stft_mel_kernel, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
+  if (a.slot_w0 && (a.kb_mask & ~kKbMaskLow) == 0)
+    hipLaunchKernelGGL(stft_mel2_kernel<kKbMaskLow>, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
+  else if (a.slot_w0)
+    hipLaunchKernelGGL(stft_mel2_kernel<kKbMaskAll>, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
+  else hipLaunchKernelGGL(stft_mel_kernel, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
   const hipError_t e = hipGetLastError();
   return e != hipSuccess ? e : launch_mel_transpose(a.mel_tm, a.mel, a.B, a.T, a.M, a.Mpad, stream);
 }
@@ -278,6 +415,10 @@ hipError_t prepare_frame_kernels() {
   hipError_t e = hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)stft_mel2_kernel<kKbMaskLow>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)stft_mel2_kernel<kKbMaskAll>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
   return e != hipSuccess ? e : prepare_gl_kernels();
 }
 

@@ -134,7 +134,7 @@ class ChunkSink:
         shape = (rows,) + tuple(row_shape)
         if to_host:
             self.out = torch.empty(shape, dtype=dtype, pin_memory=self.cuda)
-            self.side = torch.cuda.Stream(device) if self.cuda else None
+            self.side = None  # side stream, made when the first of several chunks arrives
         else:
             self.out = torch.empty(shape, dtype=dtype, device=device)
             self.side = None
@@ -149,11 +149,19 @@ class ChunkSink:
             if chunk.data_ptr() != self.out[a:b].data_ptr():
                 self.out[a:b].copy_(chunk)
             return
-        if self.side is None:
+        if not self.cuda:
             self.out[a:b].copy_(chunk)
+            return
+        if a == 0 and b == self.out.shape[0]:
+            # the whole shard in one chunk (one tile per request, server.py:152-164): nothing to overlap with, so the copy
+            # stays on the compute stream - no event, no second stream on the latency path
+            self.out.copy_(chunk, non_blocking=True)
+            self.side = torch.cuda.current_stream(self.device)
             return
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
+        if self.side is None:
+            self.side = torch.cuda.Stream(self.device)
         self.side.wait_event(done)
         with torch.cuda.stream(self.side):
             self.out[a:b].copy_(chunk, non_blocking=True)

@@ -8,7 +8,7 @@ from riffusion.spectrogram_params import SpectrogramParams
 B = int(os.environ.get("B", 64)); T = 512
 plan = _hip.get_plan(SpectrogramParams(), "cuda")
 mel = torch.rand(B, 512, T, device="cuda") ** 4 * 3e7
-for rep in range(3):
+for rep in range(5):
     torch.cuda.synchronize(); t = time.time()
     out = plan.inverse_mel(mel, 1, seed=rep)
     torch.cuda.synchronize(); dt = time.time() - t
