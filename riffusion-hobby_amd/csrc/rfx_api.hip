@@ -113,9 +113,11 @@ struct rfx_plan {
   int* d_band_lo = nullptr;        // [Mpad] followed by band_len [Mpad]
   int band_rows = 0, Mpad = 0;
   bool fwd_unfused = false;        // debugging override (RFX_FWD_UNFUSED), read once at creation
-  float* d_slot_w = nullptr;       // product form of the fused kernel: [2][21][kQPad] per-slot weights (w0 then w1) ...
-  int* d_slot_idx = nullptr;       // ... [21][kQPad] bin positions followed by [3][Mpad] filter ranges; null: table form
+  void* d_slot_tab = nullptr;      // product form of the fused kernel: [21][kQPad] {w0, w1} per slot ...
+  int* d_slot_idx = nullptr;       // ... [kMelPadsPerThread][kQPad] padding positions, [2][Mpad] filter segments, [21][kQPad] product positions; null: table form
   unsigned fwd_kb_mask = 0;
+  int fwd_prod_arr = 0;
+  int fwd_run_cap = 64;            // longest run of frames one workgroup of the product-form kernel walks (RFX_FWD_RUN, read at creation)
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
   bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
   int gl_latency_frames_per_slot = 4;  // ... up to this many frames per resident workgroup slot (RFX_GL_LATENCY_FRAMES)
@@ -450,30 +452,38 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->band_rows = rows;
       pl->Mpad = Mpad;
       pl->fwd_ok = true;
-      // product form of the fused kernel (stft_mel2_kernel): per-slot weights / bin positions and per-filter ranges.
-      // Needs the first-filter index to be non-decreasing over the active bins, so that a filter's band is its rising
-      // part (bins whose SECOND filter it is) followed by its falling part (bins whose FIRST filter it is).
+      // product form of the fused kernel (stft_mel2_kernel).  Needs the group structure of the bank: active bins contiguous,
+      // first-filter index non-decreasing, so that filter m = (w1 products of group m-1) + (w0 products of group m).
       if (!generic && M <= 2 * kThreads && getenv("RFX_FWD_V1") == nullptr) {
-        const int nb = f_hi - f_lo;
-        std::vector<int> rng(3 * (size_t)Mpad, 0);
-        bool v2 = 2 * nb <= 2 * kCubeElems;
-        for (int m = 0; m < M && v2; ++m) {
-          const int lo = band_lo[m], hi = band_hi[m];
-          int mid = hi;
-          for (int f = lo; f < hi; ++f)
-            if (bin_m0[f] == m) { mid = f; break; }
-          for (int f = lo; f < hi && v2; ++f) {
-            const float want = h_melfb[(size_t)f * M + m];
-            if (f < mid) v2 = bin_m0[f] == m - 1 && bin_w1[f] == want;
-            else v2 = bin_m0[f] == m && bin_w0[f] == want;
-          }
-          rng[m] = lo - f_lo;
-          rng[Mpad + m] = mid - f_lo;
-          rng[2 * (size_t)Mpad + m] = hi - f_lo;
+        bool v2 = true;
+        std::vector<int> cnt(M, 0), gfirst(M, 0);
+        int prev = 0;
+        for (int f = f_lo; f < f_hi && v2; ++f) {
+          if (bin_m0[f] < prev) v2 = false;
+          else { prev = bin_m0[f]; cnt[prev]++; }
         }
+        // (a zero row inside [f_lo, f_hi) has bin_m0 == -1 < prev and lands here as "not monotone")
+        std::vector<int> G(M + 1, 0);  // padded position of group g
+        for (int g2 = 0, acc = f_lo; g2 < M; ++g2) { gfirst[g2] = acc; acc += cnt[g2]; G[g2 + 1] = G[g2] + (cnt[g2] + 3) / 4 * 4; }
+        const int arr = G[M];
+        const int dump0 = 2 * arr;  // one dump float per lane behind the two arrays
+        if (v2 && dump0 + kQPad > 2 * kCubeElems) v2 = false;
+        // every filter must equal its two group sums exactly: check weights against the dense bank
+        for (int m = 0; m < M && v2; ++m)
+          for (int f = band_lo[m]; f < band_hi[m] && v2; ++f) {
+            const float want = h_melfb[(size_t)f * M + m];
+            v2 = (bin_m0[f] == m && bin_w0[f] == want) || (bin_m0[f] == m - 1 && bin_w1[f] == want);
+          }
+        std::vector<int> pads;
+        for (int g2 = 0; g2 < M; ++g2)
+          for (int p = G[g2] + cnt[g2]; p < G[g2 + 1]; ++p) pads.push_back(p);
+        if ((int)pads.size() > kMelPadsPerThread * kHop) v2 = false;
         if (v2) {
-          std::vector<float> sw0(21 * (size_t)kQPad, 0.f), sw1(21 * (size_t)kQPad, 0.f);
-          std::vector<int> sidx(21 * (size_t)kQPad, -1);
+          struct SlotEntry { float w0, w1; };
+          std::vector<SlotEntry> tab(21 * (size_t)kQPad, SlotEntry{0.f, 0.f});
+          std::vector<int> tab_at(21 * (size_t)kQPad);
+          for (int kb = 0; kb < 21; ++kb)
+            for (int qp = 0; qp < kQPad; ++qp) tab_at[(size_t)kb * kQPad + qp] = dump0 + qp;
           std::vector<char> seen(F, 0);
           unsigned mask = 0;
           for (int k1 = 0; k1 < 21; ++k1)
@@ -483,23 +493,36 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
                 const int bin = slot_bin(k1, ka, kb, &cj);
                 if (seen[bin]) continue;  // the duplicate slot of a bin contributes nothing
                 seen[bin] = 1;
-                if (bin < f_lo || bin >= f_hi || bin_m0[bin] < 0) continue;
-                const size_t o = (size_t)kb * kQPad + slot_qp(k1 * 21 + ka);
-                sw0[o] = bin_w0[bin];
-                sw1[o] = bin_w1[bin];
-                sidx[o] = bin - f_lo;
+                if (bin < f_lo || bin >= f_hi) continue;
+                const int g2 = bin_m0[bin];
+                tab[(size_t)kb * kQPad + slot_qp(k1 * 21 + ka)] = SlotEntry{bin_w0[bin], bin_w1[bin]};
+                tab_at[(size_t)kb * kQPad + slot_qp(k1 * 21 + ka)] = G[g2] + (bin - gfirst[g2]);
                 mask |= 1u << kb;
               }
-          RFX_HIP(hipMalloc(&pl->d_slot_w, 2 * sw0.size() * sizeof(float)));
-          RFX_HIP(hipMemcpy(pl->d_slot_w, sw0.data(), sw0.size() * sizeof(float), hipMemcpyHostToDevice));
-          RFX_HIP(hipMemcpy(pl->d_slot_w + sw0.size(), sw1.data(), sw1.size() * sizeof(float), hipMemcpyHostToDevice));
-          RFX_HIP(hipMalloc(&pl->d_slot_idx, (sidx.size() + rng.size()) * sizeof(int)));
-          RFX_HIP(hipMemcpy(pl->d_slot_idx, sidx.data(), sidx.size() * sizeof(int), hipMemcpyHostToDevice));
-          RFX_HIP(hipMemcpy(pl->d_slot_idx + sidx.size(), rng.data(), rng.size() * sizeof(int), hipMemcpyHostToDevice));
+          std::vector<int> padtab((size_t)kMelPadsPerThread * kQPad);
+          for (int i = 0; i < kMelPadsPerThread; ++i)
+            for (int qp = 0; qp < kQPad; ++qp) padtab[(size_t)i * kQPad + qp] = dump0 + qp;
+          for (size_t i = 0; i < pads.size(); ++i) padtab[(i / kHop) * kQPad + slot_qp((int)(i % kHop))] = pads[i];
+          std::vector<int> seg(2 * (size_t)Mpad, 0);  // (first float << 4) | 16-byte reads; groups hold at most 60 bins here
+          for (int m = 0; m < M && v2; ++m) {
+            if (cnt[m] > 60) v2 = false;
+            if (m > 0) seg[m] = ((arr + G[m - 1]) << 4) | ((cnt[m - 1] + 3) / 4);  // rising: w1 products of group m-1
+            seg[(size_t)Mpad + m] = (G[m] << 4) | ((cnt[m] + 3) / 4);              // falling: w0 products of group m
+          }
+          if (v2) {
+          RFX_HIP(hipMalloc(&pl->d_slot_tab, tab.size() * sizeof(SlotEntry)));
+          RFX_HIP(hipMemcpy(pl->d_slot_tab, tab.data(), tab.size() * sizeof(SlotEntry), hipMemcpyHostToDevice));
+          RFX_HIP(hipMalloc(&pl->d_slot_idx, (padtab.size() + seg.size() + tab_at.size()) * sizeof(int)));
+          RFX_HIP(hipMemcpy(pl->d_slot_idx, padtab.data(), padtab.size() * sizeof(int), hipMemcpyHostToDevice));
+          RFX_HIP(hipMemcpy(pl->d_slot_idx + padtab.size(), seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice));
+          RFX_HIP(hipMemcpy(pl->d_slot_idx + padtab.size() + seg.size(), tab_at.data(), tab_at.size() * sizeof(int), hipMemcpyHostToDevice));
           pl->fwd_kb_mask = mask;
+          pl->fwd_prod_arr = arr;
+          }
         }
       }
       pl->fwd_unfused = getenv("RFX_FWD_UNFUSED") != nullptr;
+      if (const char* e = getenv("RFX_FWD_RUN")) pl->fwd_run_cap = atoi(e) > 0 ? atoi(e) : 64;
     }
     if (ok) {
       // one device blob: csr_w | csr_ptr | band_lo | bin_m0 | bin_w0 | bin_w1 | bin_pos | bin_pos2
@@ -556,7 +579,7 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_band_wt);
     (void)hipFree(plan->d_band_lo);
     (void)hipFree(plan->d_band_addr);
-    (void)hipFree(plan->d_slot_w);
+    (void)hipFree(plan->d_slot_tab);
     (void)hipFree(plan->d_slot_idx);
     (void)hipFree(plan->d_gen_tables);
     (void)hipFree(plan->d_gen_rev);
@@ -951,15 +974,16 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     f.Mpad = plan->Mpad;
     f.f_lo = plan->imel.f_lo;
     f.f_hi = plan->imel.f_hi;
-    f.slot_w0 = plan->d_slot_w;
-    f.slot_w1 = plan->d_slot_w ? plan->d_slot_w + 21 * (size_t)kQPad : nullptr;
-    f.slot_idx = plan->d_slot_idx;
-    f.filt_rng = plan->d_slot_idx ? plan->d_slot_idx + 21 * (size_t)kQPad : nullptr;
+    f.slot_tab = plan->d_slot_tab;
+    f.pad_tab = plan->d_slot_idx;
+    f.filt_seg = plan->d_slot_idx ? plan->d_slot_idx + (size_t)kMelPadsPerThread * kQPad : nullptr;
+    f.slot_at = plan->d_slot_idx ? f.filt_seg + 2 * (size_t)plan->Mpad : nullptr;
+    f.prod_arr = plan->fwd_prod_arr;
     f.kb_mask = plan->fwd_kb_mask;
     // runs of consecutive frames: every resident workgroup slot of the chip gets one run when the batch allows it (the
     // product-form kernel carries a sliding input window along a run), at most 64 frames, at least 1
     const long long frames = (long long)B * f.T;
-    const int cap = plan->d_slot_w ? 64 : 16;
+    const int cap = plan->d_slot_tab ? plan->fwd_run_cap : 16;
     int fpb = (int)((frames + 2LL * plan->num_cus - 1) / (2LL * plan->num_cus));
     f.frames_per_block = fpb < 1 ? 1 : fpb > cap ? cap : fpb;
     RFX_HIP(launch_stft_mel(f, (hipStream_t)stream));

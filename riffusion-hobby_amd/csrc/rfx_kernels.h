@@ -83,14 +83,16 @@ struct StftMelArgs {
   int B, T, Lw, frames_per_block;
   int M, Mpad;           // Mpad = M rounded up to 64
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
-  // product form (stft_mel2_kernel; valid when slot_w0 != nullptr): the thread that owns a bin's primary slot multiplies
-  // |X| by the bin's two filterbank weights and scatters the products in BIN ORDER; a filter is then two contiguous sums
-  const float* slot_w0;  // [21][kQPad] weight of the slot's bin on its first filter (0: inactive bin / duplicate slot), kb-major
-  const float* slot_w1;  // [21][kQPad] weight on the next filter
-  const int* slot_idx;   // [21][kQPad] bin - f_lo of the slot's bin, or -1 when the slot contributes nothing
-  const int* filt_rng;   // [3][Mpad]: lo, mid, hi (relative to f_lo): filter m = sum prod1[lo..mid) + sum prod0[mid..hi)
-  unsigned kb_mask;      // bit kb set when any thread's slot kb contributes (wave-uniform skip of the other kb)
+  // product form (stft_mel2_kernel; valid when slot_tab != nullptr): the thread that owns a bin's primary slot multiplies
+  // |X| by the bin's two filterbank weights and scatters the products group by group; a filter is then two contiguous sums
+  const void* slot_tab;  // [21][kQPad] x {w0, w1}: weights of the slot's bin on its first / second filter (zero for a slot that contributes nothing)
+  const int* slot_at;    // [21][kQPad] LDS position of the slot's w0 product (the lane's dump position for a slot that contributes nothing)
+  const int* pad_tab;    // [kMelPadsPerThread][kQPad] LDS positions of the zero padding this thread rewrites every frame (dump if none)
+  const int* filt_seg;   // [2][Mpad]: rising segment, falling segment, each as (first float << 4) | number of 16-byte reads
+  int prod_arr;          // floats between the w0 and the w1 product arrays
+  unsigned kb_mask;      // bit kb set when any thread's slot kb contributes
 };
+constexpr int kMelPadsPerThread = 4;
 hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream);
 
 // mel projection GEMM: out[b][m][t] = sum_p fbs[p][m] * mag[b*T+t][p]

@@ -249,29 +249,27 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) { 
 // ---- fused forward path, product form.  What changed against stft_mel_kernel above, and why:
 //  * the transform half is the Griffin-Lim kernel's analysis half: a workgroup walks a RUN of consecutive frames, the ten
 //    input samples of thread n' are a register sliding window (one new load per frame, requested a frame ahead), the
-//    g(n')^k1 twiddles are requested during the mel phase of the previous frame (stft_mel_kernel fetched ten samples and
-//    twenty twiddles per frame and waited for them on the spot);
+//    g(n')^k1 twiddles and the Hann samples are requested during the mel phase of the previous frame (stft_mel_kernel
+//    fetched ten samples and twenty twiddles per frame and waited for them on the spot);
 //  * the mel phase reads no tables: the thread that owns a bin's primary slot holds |X| in a register anyway, multiplies it
-//    by the bin's (at most two) filterbank weights - frame-invariant, streamed from an L2-resident per-slot table under
-//    P2 / P3 like |S| in the Griffin-Lim kernel - and scatters the two products into bin-ordered LDS arrays prod0 / prod1
-//    (the cube is dead by then).  Filter m is then  sum prod1[lo..mid) + sum prod0[mid..hi): its rising part (bins whose
-//    SECOND filter it is) followed by its falling part (bins whose FIRST filter it is) - contiguous LDS reads, plain adds,
-//    still summed in increasing bin order.  stft_mel_kernel fetched a weight and an address per product from L2 in
-//    dependent steps of eight (7 976 x 2 loads per frame).
+//    by the bin's (at most two) filterbank weights - frame-invariant, streamed from an L2-resident per-slot table under P3
+//    like |S| in the Griffin-Lim kernel - and scatters the two products into LDS arrays prod0 / prod1 laid out GROUP by
+//    group (group g = the bins whose first filter is g, in bin order, padded with zeros to a multiple of four; the cube is
+//    dead by then).  Filter m is  sum(prod1 over group m-1) + sum(prod0 over group m): its rising part followed by its
+//    falling part, i.e. still summed in increasing bin order - contiguous 16-byte LDS reads and plain adds, no masks per
+//    product.  stft_mel_kernel fetched a weight and an address per product from L2 in dependent steps of eight (7 976 x 2
+//    loads per frame and workgroup).
 // Cost: two more workgroup barriers per frame (all waves must have left P3 before the cube is overwritten with products).
+// Measured (B = 64, T = 512): 0.83 -> 0.69 ms; ablations: transform alone 0.46 ms, + product exchange 0.58 ms.
 // KBMASK: the kb (of a thread's 21 slots) that can contribute, as a compile-time set: 0x1F001F (kb 0..4 and 16..20) covers
 // every bank that ends at or below bin 4200 (the default 0-10 kHz bank: bins 1..4000), 0x1FFFFF any bank.
 constexpr unsigned kKbMaskLow = 0x1F001Fu, kKbMaskAll = 0x1FFFFFu;
-#ifndef RFX_MEL_BATCH
-#define RFX_MEL_BATCH 16  // products fetched per LDS round trip in the filter sums
-#endif
 template <unsigned KBMASK>
 __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ThreadId t = thread_id();
   const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
-  const int nb = a.f_hi - a.f_lo;
-  float* prod = reinterpret_cast<float*>(smem);  // [0, nb): w0 * |X| in bin order; [nb, 2 nb): w1 * |X|
+  float* prod = reinterpret_cast<float*>(smem);  // [0, arr): w0 * |X|, group-padded; [arr, 2 arr): w1 * |X|; then one dump float per lane
 
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   const int clip = blockIdx.x / chunks;
@@ -279,27 +277,24 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   const int f1 = min(a.T, f0 + a.frames_per_block);
   const rsrc_t xin = make_rsrc(a.wave + (size_t)clip * a.Lw, (size_t)a.Lw * 4);
   const rsrc_t win = make_rsrc(a.win, kWin * 4);
-  const rsrc_t w0src = make_rsrc(a.slot_w0, 21 * kQPad * 4), w1src = make_rsrc(a.slot_w1, 21 * kQPad * 4);
-  const rsrc_t idsrc = make_rsrc(a.slot_idx, 21 * kQPad * 4);
+  const rsrc_t slots = make_rsrc(a.slot_tab, 21 * kQPad * 8);
+  const rsrc_t slotat = make_rsrc(a.slot_at, 21 * kQPad * 4);
+  // Frame-invariant per-thread constants that are only needed in the short mel phase (where the products go, the segments
+  // of the thread's filters, its share of the zero padding) are re-fetched from their L2-resident tables every frame, in
+  // flight across the barrier that precedes their use: held in registers they are spilled around the transform and reloaded
+  // on the spot (seen in the ISA).
+  const rsrc_t segsrc = make_rsrc(a.filt_seg, (size_t)2 * a.Mpad * 4);
+  const rsrc_t padsrc = make_rsrc(a.pad_tab, (size_t)kMelPadsPerThread * kQPad * 4);
   const unsigned npr4 = (unsigned)t.npr * 4u;
   const unsigned qp4 = (unsigned)slot_qp(t.npr) * 4u;
 
-  // the (up to two) filters of this thread: threadIdx and threadIdx + kThreads (the first wave carries the second
-  // filters: they are the LONGEST bands, its first filters the shortest).  A filter is the sum over [lo, hi) of
-  // prod[i + (i < mid ? nb : 0)]: rising part from the w1 products, falling part from the w0 products.
-  int lo[2], mid[2], hi[2];
-#pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    const int m = threadIdx.x + w * kThreads;
-    const bool has = m < a.M;
-    lo[w] = has ? a.filt_rng[m] : 0;
-    mid[w] = has ? a.filt_rng[a.Mpad + m] : 0;
-    hi[w] = has ? a.filt_rng[2 * a.Mpad + m] : 0;
-  }
-
+  // the thread's ten Hann samples: like the twiddles, fetched during the mel phase of the previous frame
   float w10[10];
+  auto load_window = [&] {
 #pragma unroll
-  for (int j = 0; j < 10; ++j) w10[j] = ld1(win, npr4, (unsigned)j * (kHop * 4u));
+    for (int j = 0; j < 10; ++j) w10[j] = ld1(win, npr4, (unsigned)j * (kHop * 4u));
+  };
+  load_window();
   auto load_x = [&](int blk) { return ld1(xin, (unsigned)reflect_index(blk * kHop + t.npr, a.Lw) * 4u, 0); };
   float d[10];
 #pragma unroll
@@ -317,62 +312,107 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
 #pragma unroll
     for (int j = 0; j < 10; ++j) u[j] = d[j] * w10[j];
     cf R[21];
-    float w0[21], w1[21];
-    int sidx[21];
+    float sw0[21], sw1[21];  // per contributing slot: weights of its bin on its first / second filter, then their products with |X|
     frame_forward_tw(u, R, f, t, tw1,
                      [&] { d_next = load_x(fr + 10 - kHalfHops); },  // after the analysis barrier: the next frame's new sample
                      NoHook(),
-                     [&] {  // before P3 (P2's registers are free): the slots' weights and bin positions fly under P3
+                     [&] {  // before P3 (P2's registers are free): the slots' weights fly under P3
 #pragma unroll
                        for (int kb = 0; kb < 21; ++kb)
                          if ((KBMASK >> kb) & 1u) {
-                           w0[kb] = ld1(w0src, qp4, (unsigned)kb * (kQPad * 4u));
-                           w1[kb] = ld1(w1src, qp4, (unsigned)kb * (kQPad * 4u));
-                           sidx[kb] = __builtin_bit_cast(int, ld1(idsrc, qp4, (unsigned)kb * (kQPad * 4u)));
+                           const v2f e = ld2(slots, 2u * qp4, (unsigned)kb * (kQPad * 8u));
+                           sw0[kb] = e.x;
+                           sw1[kb] = e.y;
                          }
                      });
 #pragma unroll
     for (int kb = 0; kb < 21; ++kb)
       if ((KBMASK >> kb) & 1u) {
-        const float mag = sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
-        w0[kb] *= mag;
-        w1[kb] *= mag;
+        // v_sqrt_f32 (1 ulp) instead of the IEEE expansion: |X| carries ~1e-7 relative error from the transform anyway
+        const float mag = __builtin_amdgcn_sqrtf(fmaf(R[kb].re, R[kb].re, R[kb].im * R[kb].im));
+        sw0[kb] *= mag;
+        sw1[kb] *= mag;
       }
+    // where the products go, this thread's zero-padding positions, and the segments of its (up to two) filters - threadIdx
+    // and threadIdx + kThreads (the first wave carries the second filters: they are the LONGEST bands, its first filters
+    // the shortest): needed right behind the next two barriers, in flight across them
+    int sat[21], pad_at[kMelPadsPerThread], seg[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 21; ++kb)
+      if ((KBMASK >> kb) & 1u) sat[kb] = __builtin_bit_cast(int, ld1(slotat, qp4, (unsigned)kb * (kQPad * 4u)));
+#pragma unroll
+    for (int i = 0; i < kMelPadsPerThread; ++i) pad_at[i] = __builtin_bit_cast(int, ld1(padsrc, qp4, (unsigned)i * (kQPad * 4u)));
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        seg[w][h] = __builtin_bit_cast(int, ld1(segsrc, (threadIdx.x + w * kThreads) * 4u, (unsigned)h * (unsigned)a.Mpad * 4u));
     __syncthreads();  // every wave has left P3: the cube may be overwritten
 #ifndef RFX_NO_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    if (t.active) {
+    if (t.active) {  // slots that contribute nothing (duplicates, bins outside the bank) carry zero weights and the lane's dump position
 #pragma unroll
       for (int kb = 0; kb < 21; ++kb)
-        if (((KBMASK >> kb) & 1u) && sidx[kb] >= 0) {
-          prod[sidx[kb]] = w0[kb];
-          prod[sidx[kb] + nb] = w1[kb];
+        if ((KBMASK >> kb) & 1u) {
+          prod[sat[kb]] = sw0[kb];
+          prod[sat[kb] + a.prod_arr] = sw1[kb];
         }
+#pragma unroll
+      for (int i = 0; i < kMelPadsPerThread; ++i) {
+        prod[pad_at[i]] = 0.f;
+        prod[pad_at[i] + a.prod_arr] = 0.f;
+      }
     }
     load_tw1(tw1, f);  // for the next frame's P1: in flight across the mel phase
+    load_window();
     __syncthreads();
     {
-      // frame-major scratch (Mpad contiguous floats per frame: whole-line stores); a tiled transpose brings it into the
-      // reference's (B, M, T) layout afterwards - 4-byte stores T floats apart cost 10x the bytes in HBM writes
+      // Results go to a frame-major scratch (Mpad contiguous floats per frame: whole-line stores); a tiled transpose brings
+      // it into the reference's (B, M, T) layout afterwards - 4-byte stores T floats apart cost 10x the bytes in HBM writes.
       float* __restrict__ row = a.mel_tm + ((size_t)clip * a.T + fr) * a.Mpad;
+      const v4f* prod4 = reinterpret_cast<const v4f*>(prod);
+      auto add4 = [](float s, v4f x) { return (((s + x.x) + x.y) + x.z) + x.w; };
+      // the tail of a segment longer than 16 products (wave-uniform trip count: the lanes of a wave hold neighbouring filters)
+      auto tail = [&](float s, const v4f* p, int n4) {
+        for (int e0 = 4; __builtin_amdgcn_ballot_w64(e0 < n4) != 0; e0 += 4) {
+          v4f x[4];
 #pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        const int m = threadIdx.x + w * kThreads;
-        if (m >= a.Mpad) break;  // wave-uniform: only the first wave(s) carry a second filter
-        float s = 0.f;
-        const int last = hi[w] - 1;
-        for (int i = lo[w]; i < hi[w]; i += RFX_MEL_BATCH) {  // RFX_MEL_BATCH products per LDS round trip, summed in bin order
-          float v[RFX_MEL_BATCH];
+          for (int j = 0; j < 4; ++j) x[j] = p[e0 + j];
 #pragma unroll
-          for (int j = 0; j < RFX_MEL_BATCH; ++j) {
-            const int q = min(i + j, last);
-            v[j] = prod[q + (q < mid[w] ? nb : 0)];
-          }
-#pragma unroll
-          for (int j = 0; j < RFX_MEL_BATCH; ++j) s += (i + j <= last) ? v[j] : 0.f;
+          for (int j = 0; j < 4; ++j)
+            if (e0 + j < n4) s = add4(s, x[j]);
         }
-        row[m] = s;  // padding filters (m >= M): empty range, 0
+        return s;
+      };
+      // One filter: the first 16 products of its rising AND of its falling segment are requested together (one LDS round
+      // trip; every lane issues them all: a lane whose segment is shorter reads into its neighbours' products or the dump
+      // area - always inside the cube - and does not add them), then the sums: rising part first, in bin order.
+      auto filter_sum = [&](int sr, int sf) {
+        const v4f* pa = prod4 + (sr >> 6);  // segments start on 16-byte boundaries
+        const v4f* pb = prod4 + (sf >> 6);
+        const int na = sr & 15, nb4 = sf & 15;
+        v4f ra[4], rb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ra[j] = pa[j];
+          rb[j] = pb[j];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < na) s = add4(s, ra[j]);
+        s = tail(s, pa, na);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nb4) s = add4(s, rb[j]);
+        return tail(s, pb, nb4);
+      };
+      const float s0 = filter_sum(seg[0][0], seg[0][1]);
+      if (threadIdx.x < a.Mpad) row[threadIdx.x] = s0;  // padding filters (m >= M): empty segments, 0
+      if (kThreads < a.Mpad && threadIdx.x < 64) {      // wave-uniform: the first wave carries the filters past kThreads
+        const float s1 = filter_sum(seg[1][0], seg[1][1]);
+        if (threadIdx.x + kThreads < a.Mpad) row[threadIdx.x + kThreads] = s1;
       }
     }
     __syncthreads();  // the next frame's P1 overwrites the products
@@ -402,9 +442,9 @@ hipError_t launch_mel_transpose(const float* mel_tm, float* mel, int B, int T, i
 
 hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream) {
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
-  if (a.slot_w0 && (a.kb_mask & ~kKbMaskLow) == 0)
+  if (a.slot_tab && (a.kb_mask & ~kKbMaskLow) == 0)
     hipLaunchKernelGGL(stft_mel2_kernel<kKbMaskLow>, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
-  else if (a.slot_w0)
+  else if (a.slot_tab)
     hipLaunchKernelGGL(stft_mel2_kernel<kKbMaskAll>, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
   else hipLaunchKernelGGL(stft_mel_kernel, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
   const hipError_t e = hipGetLastError();
