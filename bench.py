@@ -95,15 +95,19 @@ class stdout_to_stderr:
         return False
 
 
-def git_rev(path: str) -> str:
-    """Short hash of the last commit that touched `path` (provenance of numbers read from profiles/)."""
+def profile_rev(summary: dict, path: str) -> str:
+    """Commit the binaries were built from when the PMC summary `path` was collected.  The hash is written INTO the summary
+    by the script that generates it (tools/profile_round.sh reads .git_rev, which tools/gpu.sh ships to the GPU box - the
+    pushed snapshot has no .git); older summaries fall back to the last commit that touched the file."""
+    if summary.get("git"):
+        return str(summary["git"])
     import subprocess
 
     try:
         return subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True,
-                              text=True, timeout=10).stdout.strip() or "untracked"
+                              text=True, timeout=10).stdout.strip() or "not recorded"
     except Exception:
-        return "unknown"
+        return "not recorded"
 
 
 def pmc_summary():
@@ -270,21 +274,26 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
         except Exception:
             fpmc = {}
         fscale = B / float(fpmc.get("batch_tiles", 64))
-        roof = {"kernel": "rfx::stft_mel_kernel", "bound": "hbm", "achieved": round(alg_bytes / (mel_ms * 1e-3) / 1e9, 1),
+        # what the fused kernel really computes per launch: the pruned real FFTs (2.5 N log2 N per frame) and the BANDED mel
+        # projection (2 x 7 976 flops per frame); against the fp32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s)
+        true_flop = B * N_FRAMES * (2.5 * 17640 * np.log2(17640) + 2.0 * 7976)
+        roof = {"kernel": fpmc.get("kernel", "rfx::stft_mel2_kernel"), "bound": "hbm", "achieved": round(alg_bytes / (mel_ms * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (mel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "traffic": fpmc.get("hbm_bytes_per_launch") * fscale if fpmc.get("hbm_bytes_per_launch") else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(mel_ms, 4),
-                "dense_equivalent_tflops": round(dense_flop / (mel_ms * 1e-3) / 1e12, 1),
+                "true_flops_per_launch": true_flop, "true_tflops": round(true_flop / (mel_ms * 1e-3) / 1e12, 2),
+                "true_flops_frac": round(true_flop / (mel_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "note": "fused framed transform -> |X| -> banded mel projection in one launch: the mel GEMM of the reference (4.6 of its "
-                        "4.94 GFLOP per tile) multiplies a banded filterbank (7 976 non-zeros of 4.5 M) and is evaluated as such on chip, "
-                        "so neither HBM nor the MFMA pipes bound this kernel; dense_equivalent_tflops prices the launch at the "
-                        "reference's dense flop count (label: dense-equivalent, SURVEY 8(d)); `binding` is the resource that does"}
+                        "4.94 GFLOP per tile) multiplies a banded filterbank (7 976 non-zeros of 4.5 M) and is evaluated as such on chip, so "
+                        "neither HBM nor the MFMA pipes bound this kernel: `frac` (HBM) is small by construction, true_flops_frac prices the "
+                        "flops actually executed against the 157.3 TFLOP/s fp32 peak, and `binding` (VALU issue) is the resource that bounds it; "
+                        "avg_launch_ms is one launch between two stream drains (HIP events)"}
         valu = fpmc.get("SQ_INSTS_VALU_per_launch")
         if valu:
             valu *= fscale
             got = valu / (mel_ms * 1e-3) / 1e9
             roof["binding"] = {"bound": "valu", "unit": "G wave-instructions/s", "wave_instructions_per_launch": valu, "achieved": round(got, 1),
                                "peak": 1228.8, "frac": round(got / 1228.8, 4), "sustained_peak": round(1024 / 1.13, 1),
-                               "frac_of_sustained": round(got / (1024 / 1.13), 4), "source": pmc_src, "git": git_rev(pmc_src)}
+                               "frac_of_sustained": round(got / (1024 / 1.13), 4), "source": pmc_src, "git": profile_rev(fpmc, pmc_src)}
         k_exec = executed_mel_k()
         out = {
             "metric": "spectrogram_images_per_sec_forward",
@@ -535,10 +544,12 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(avg_ms, 4),
             "measured_in_this_run": ["avg_launch_ms", "achieved", "frac"],
+            "avg_launch_ms_note": "mean of the steady-state launches of one rfx_griffinlim_timed call, each bracketed by its own pair of HIP events on the "
+                                  "launch stream: consecutive launches cannot overlap their tails there, so iterations x avg_launch_ms exceeds stages.griffinlim_ms slightly",
             # counters cannot be collected from inside the timed process: these fields are read from the committed
             # rocprofv3 --pmc summary of the same kernel (re-collected whenever the kernel changes)
             "from_profiles": {"fields": ["traffic", "actual_hbm_gbs", "actual_hbm_frac", "binding.wave_instructions_per_launch"],
-                              "source": pmc_src, "git": git_rev(pmc_src)},
+                              "source": pmc_src, "git": profile_rev(fpmc, pmc_src)},
             # `achieved` prices the kernel against the CANONICAL fused formulation of SURVEY 8(d) (|S| 4 B + tprev
             # 8 B read + 8 B written per bin and iteration: an HBM-bound kernel).  The shipped kernel applies the
             # momentum in the time domain (STFT linearity), streams only |S| (`traffic` is what it really moves)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU visit: rocprofv3 kernel stats of the bench command, then PMC passes (each counter group in its own run, with
-# --kernel-trace only) for the two dominant kernels: rfx::gl_iter_kernel<2> (decode) and rfx::stft_mel_kernel (forward).
+# --kernel-trace only) for the two dominant kernels: rfx::gl_iter_kernel<2> (decode) and rfx::stft_mel2_kernel (forward).
+# The InverseMelScale kernel has its own script (tools/pmc_imel.sh: 64-tile launches only).
 # Summaries land in gpurun_out/prof/; copy the ones to be judged into profiles/.
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
@@ -29,12 +30,16 @@ names = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_
          "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
          "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "GRBM_COUNT"]
 tables = {c: agg(c) for c in names}
-for key, fname in (("gl_iter_kernel<2>", "gl_iter_pmc.json"), ("stft_mel_kernel", "forward_pmc.json"), ("imel_group_kernel", "imel_pmc.json")):
+try:
+    rev = open("$R/.git_rev").read().strip()   # written by tools/gpu.sh: the pushed snapshot has no .git
+except Exception:
+    rev = "not recorded"
+for key, fname in (("gl_iter_kernel<2>", "gl_iter_pmc.json"), ("stft_mel2_kernel", "forward_pmc.json")):
     res = {}
     for k in tables["FETCH_SIZE"]:
         if key not in k: continue
         f_kb = tables["FETCH_SIZE"][k][1]; w_kb = tables["WRITE_SIZE"].get(k, (0, 0.0))[1]
-        res = {"kernel": k, "batch_tiles": 64, "frames_per_tile": 512, "launches_sampled": tables["FETCH_SIZE"][k][0], "FETCH_SIZE_kb_raw": f_kb, "WRITE_SIZE_kb_raw": w_kb,
+        res = {"kernel": k, "git": rev, "batch_tiles": 64, "frames_per_tile": 512, "launches_sampled": tables["FETCH_SIZE"][k][0], "FETCH_SIZE_kb_raw": f_kb, "WRITE_SIZE_kb_raw": w_kb,
                "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0,
                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE uncorrected; "
                        "each counter group collected in its own rocprofv3 --kernel-trace --pmc run of bench.py"}
