@@ -148,7 +148,27 @@ def audio_to_images_batch(*, audio_dir: str, output_dir: str, image_extension: s
                                sample_rate=sample_rate)
     converter = SpectrogramImageConverter(params=params, device=device)
     channels = 1 if mono else 2
-    loaded: T.Dict[int, T.List[T.Tuple[str, np.ndarray]]] = {}
+    # Streaming: files are decoded one at a time and grouped by sample count (a GPU call needs equal lengths); a group is
+    # converted and released as soon as it holds `batch_size` clips, and when the waveforms held in host memory pass
+    # `max_pending_bytes` the LARGEST group is flushed early - a directory of long clips of many different lengths never
+    # sits in RAM as a whole (the reference streams one file per thread-pool task, cli.py:172-204).
+    max_pending_bytes = 2 << 30
+    pending: T.Dict[int, T.List[T.Tuple[str, np.ndarray]]] = {}
+    pending_bytes = 0
+
+    def flush(n_samples: int) -> None:
+        nonlocal pending_bytes
+        chunk = pending.pop(n_samples)
+        pending_bytes -= sum(w.nbytes for _, w in chunk)
+        images, max_values = converter.spectrogram_images_from_waveforms(torch.from_numpy(np.stack([w for _, w in chunk])))
+        for (path, _), image, mx in zip(chunk, images, max_values):
+            exif_data = params.to_exif()
+            exif_data[SpectrogramParams.ExifTags.MAX_VALUE.value] = float(mx)
+            image.getexif().update(exif_data.items())
+            out = os.path.join(output_dir, os.path.splitext(os.path.basename(path))[0] + "." + image_extension)
+            image.save(out, exif=image.getexif(), format=image_format)
+        print(f"Wrote {len(chunk)} images to {output_dir}")
+
     for path in paths:
         try:
             seg = _load_segment(path)
@@ -159,18 +179,16 @@ def audio_to_images_batch(*, audio_dir: str, output_dir: str, image_extension: s
         if seg.frame_rate != params.sample_rate:
             seg = seg.set_frame_rate(params.sample_rate)
         wave = np.array([c.get_array_of_samples() for c in seg.split_to_mono()]).astype(np.float32)
-        loaded.setdefault(wave.shape[1], []).append((path, wave))
-    for _n, members in loaded.items():
-        for i in range(0, len(members), batch_size):
-            chunk = members[i : i + batch_size]
-            images, max_values = converter.spectrogram_images_from_waveforms(torch.from_numpy(np.stack([w for _, w in chunk])))
-            for (path, _), image, mx in zip(chunk, images, max_values):
-                exif_data = params.to_exif()
-                exif_data[SpectrogramParams.ExifTags.MAX_VALUE.value] = float(mx)
-                image.getexif().update(exif_data.items())
-                out = os.path.join(output_dir, os.path.splitext(os.path.basename(path))[0] + "." + image_extension)
-                image.save(out, exif=image.getexif(), format=image_format)
-            print(f"Wrote {len(chunk)} images to {output_dir}")
+        del seg
+        group = pending.setdefault(wave.shape[1], [])
+        group.append((path, wave))
+        pending_bytes += wave.nbytes
+        if len(group) >= batch_size:
+            flush(wave.shape[1])
+        while pending_bytes > max_pending_bytes and pending:
+            flush(max(pending, key=lambda n: sum(w.nbytes for _, w in pending[n])))
+    for n_samples in sorted(pending):
+        flush(n_samples)
 
 
 _COMMANDS: T.Dict[str, T.Callable[..., None]] = {

@@ -165,41 +165,57 @@ class PcmSegment:
     def _frames_of_ms(self, ms: float) -> int:
         return int(ms * (self.frame_rate / 1000.0))
 
-    def _slice_ms(self, start_ms: T.Optional[int], end_ms: T.Optional[int]) -> "PcmSegment":
-        n = self._data.shape[0]
+    def _parse_position(self, val: float) -> int:
+        """pydub AudioSegment._parse_position: milliseconds (negative = from the end, measured on the ROUNDED length in ms) -> frame index."""
+        if val < 0:
+            val = len(self) - abs(val)
+        return int(self._frames_of_ms_f(len(self) if val == float("inf") else val))
+
+    def _frames_of_ms_f(self, ms: float) -> float:
+        return ms * (self.frame_rate / 1000.0)
+
+    def _slice_ms(self, start_ms: T.Optional[float], end_ms: T.Optional[float]) -> "PcmSegment":
+        """pydub AudioSegment.__getitem__(slice(start_ms, end_ms)): bounds clipped to len(self) - the length ROUNDED to whole
+        milliseconds - so `seg[a:]` drops the frames past the last whole millisecond of a clip that is not a whole number of ms
+        long, and a slice whose end lies past the data (the length rounded UP) is padded with silence (at most 2 ms, like pydub,
+        which raises beyond that)."""
         length_ms = len(self)
-        lo = 0 if start_ms is None else (start_ms + length_ms if start_ms < 0 else start_ms)
-        hi = length_ms if end_ms is None else (end_ms + length_ms if end_ms < 0 else end_ms)
-        a = min(n, max(0, self._frames_of_ms(max(0, lo))))
-        b = n if end_ms is None else min(n, max(0, self._frames_of_ms(min(length_ms, max(0, hi)))))
-        return PcmSegment(self._data[a:b], self.frame_rate)
+        start = 0 if start_ms is None else min(start_ms, length_ms)
+        end = length_ms if end_ms is None else min(end_ms, length_ms)
+        a, b = self._parse_position(start), self._parse_position(end)
+        data = self._data[a:b] if b > a else self._data[0:0]
+        missing = max(0, b - a) - data.shape[0]
+        if missing > 0:
+            if missing > self._frames_of_ms_f(2):
+                raise ValueError(f"slice is missing {missing} frames (pydub: TooManyMissingFrames)")
+            data = np.concatenate([data, np.zeros((missing, self.channels), dtype=np.int16)])
+        return PcmSegment(data, self.frame_rate)
 
     def _fade(self, to_gain: float = 0.0, from_gain: float = 0.0) -> "PcmSegment":
-        """pydub AudioSegment.fade over the WHOLE segment (start=0, end=inf), as append() calls it: fades of more
-        than 100 ms step the gain once per millisecond, shorter ones once per frame; each step is an audioop.mul."""
+        """pydub AudioSegment.fade(to_gain, from_gain, start=0, end=inf), as append() calls it: the result is REBUILT from
+        pieces - fades of more than 100 ms from the one-millisecond slices self[i] (gain stepped once per millisecond), shorter
+        ones frame by frame - followed by self[len(self):], which is empty: frames past the last whole millisecond are dropped,
+        exactly as pydub drops them.  Each step is an audioop.mul."""
+        if to_gain == 0 and from_gain == 0:
+            return self
         duration = len(self)
         from_power = 10 ** (float(from_gain) / 20)
         gain_delta = 10 ** (float(to_gain) / 20) - from_power
-        out = np.empty_like(self._data)
-        n = self._data.shape[0]
         mul = (lambda x, f: np.frombuffer(_audioop.mul(np.ascontiguousarray(x).tobytes(), 2, f), dtype=np.int16).reshape(x.shape)) \
             if _audioop is not None else self._mul_np
-        pos = 0
+        pieces = []
         if duration > 100:
             scale_step = gain_delta / duration
-            for i in range(duration):  # chunk i = self[i] = frames [ms i, ms i+1)
-                a, b = self._frames_of_ms(i), self._frames_of_ms(i + 1)
-                out[a:b] = mul(self._data[a:b], from_power + scale_step * i)
-                pos = b
+            for i in range(duration):  # chunk i = self[i] = self[i : i + 1]
+                pieces.append(mul(self._slice_ms(i, i + 1)._data, from_power + scale_step * i))
         else:
-            fade_frames = float(self._frames_of_ms(duration))
+            fade_frames = self._frames_of_ms_f(duration)
             scale_step = gain_delta / fade_frames if fade_frames else 0.0
             for i in range(int(fade_frames)):
-                out[i : i + 1] = mul(self._data[i : i + 1], from_power + scale_step * i)
-                pos = i + 1
-        if pos < n:  # after the fade: the end gain
-            out[pos:] = mul(self._data[pos:], 10 ** (float(to_gain) / 20)) if to_gain != 0 else self._data[pos:]
-        return PcmSegment(out, self.frame_rate)
+                pieces.append(mul(self._data[i : i + 1], from_power + scale_step * i))
+        after = self._slice_ms(duration, None)._data  # self[end:] with end = len(self): empty
+        pieces.append(mul(after, 10 ** (float(to_gain) / 20)) if to_gain != 0 else after)
+        return PcmSegment(np.concatenate(pieces) if pieces else self._data[0:0], self.frame_rate)
 
     def overlay(self, other: "PcmSegment") -> "PcmSegment":
         """pydub AudioSegment.overlay(seg) at position 0 without looping: audioop.add over the overlap

@@ -323,6 +323,38 @@ def test_stitch_and_overlay_segments():
     assert ov.frame_count() == rate and z[0] == 32767 - 3000 and z[-1] == 32767
 
 
+def test_stitch_of_clips_that_are_not_whole_milliseconds():
+    """pydub slices by MILLISECONDS on the length rounded to whole ms (AudioSegment.__getitem__ / _parse_position) and rebuilds
+    a faded segment from one-millisecond pieces: a clip of 5110.4 ms loses the frames past ms 5110 of its head when it is
+    sliced `[:-crossfade]`, and its crossfade tail `[-crossfade:]` starts at (5110 - crossfade) ms."""
+    rate = 44100
+    n = 441 * 511 + 17  # 5110.385 ms: len() == 5110
+    a = audio_util.PcmSegment(np.arange(n, dtype=np.int64).astype(np.int16).reshape(-1, 1), rate)
+    assert len(a) == 5110
+    r = rate / 1000.0
+    # seg[a:b] = frames [int(a_ms * r), int(b_ms * r)); None bounds mean 0 / len(self) in ms
+    assert a._slice_ms(None, None).frame_count() == int(5110 * r) == n - 17
+    assert a._slice_ms(-100, None).frame_count() == int(5110 * r) - int(5010 * r)
+    assert a._slice_ms(None, -100).frame_count() == int(5010 * r)
+    assert np.array_equal(a._slice_ms(7, 9)._data, a._data[int(7 * r) : int(9 * r)])
+    # a length that rounds UP (x.6 ms): the slice to len(self) is padded with silence like pydub does (<= 2 ms)
+    up = audio_util.PcmSegment(np.ones((int(10.6 * r), 1), np.int16), rate)
+    assert len(up) == 11 and up._slice_ms(None, None).frame_count() == int(11 * r)
+    assert up._slice_ms(None, None)._data[-1, 0] == 0 and up._slice_ms(None, None)._data[int(10.6 * r) - 1, 0] == 1
+    # fade: rebuilt from 1-ms pieces + the (empty) remainder past len(self) ms
+    faded = a._slice_ms(-200, None)._fade(to_gain=-120)
+    tail = a._slice_ms(-200, None)
+    assert faded.frame_count() == int(len(tail) * r)
+    b = audio_util.PcmSegment(np.full((n, 1), 500, np.int16), rate)
+    out = a.append(b, crossfade=200)
+    head = int(4910 * r)
+    xf = int(len(tail) * r)
+    rest = int(5110 * r) - int(200 * r)
+    assert out.frame_count() == head + xf + rest
+    assert np.array_equal(out._data[:head], a._data[:head])
+    assert np.all(out._data[head + xf :] == 500)
+
+
 @pytest.mark.skipif(_ao is None, reason="audioop removed from this interpreter")
 def test_set_frame_rate_is_audioop_ratecv():
     rng = np.random.default_rng(2)
