@@ -127,6 +127,7 @@ struct rfx_plan {
   GenTables gt{};
   void* d_gen_tables = nullptr;
   int* d_gen_rev = nullptr;
+  cf* d_gen_tw = nullptr;
   int frame_stride = kFrameStride;
 };
 
@@ -216,9 +217,24 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     if (gg.nc > kGenMaxNc)
       return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: n_fft = " + std::to_string(params->n_fft) + " needs more than the 160 KiB of LDS a "
                   "workgroup has for its two FFT buffers (supported: n_fft <= 20000 when even, <= 10000 when odd)");
+    gg.nthr = 512;
     if (!gen_factor(gg.nc, gg.radix, &gg.nstages))
       return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: FFT length " + std::to_string(gg.nc) + " (from n_fft = " + std::to_string(params->n_fft) +
                   ") has a prime factor above 13; implemented radices: 2, 3, 4, 5, 7, 11, 13");
+    // threads per workgroup: measured on MI355X, the engine is latency bound and more waves win over fuller rounds
+    // (48 kHz, 64 tiles x 32 iterations: 512 threads 121 ms, 384: 134, 320 - the count gen_pick_threads prefers: 155, 256: 163)
+    gg.nthr = 512;
+    if (const char* e = getenv("RFX_GEN_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 512 && v % 64 == 0) gg.nthr = v; }
+    {  // LDS padding: keep as many workgroups per CU as the unpadded buffer allows
+      const size_t tables = sizeof(cf) * (2 * (size_t)kGenTwLo + gg.nhi + gg.nhi2);
+      const size_t plain = sizeof(cf) * (size_t)gg.nc + tables + 512;
+      int per_cu = (int)((160u * 1024u) / plain);
+      if (per_cu < 1) per_cu = 1;
+      if (per_cu > 1024 / gg.nthr) per_cu = 1024 / gg.nthr;
+      const size_t room = (160u * 1024u) / per_cu - tables - 512;
+      gg.pad_shift = gen_pick_pad(gg, (int)(room / sizeof(cf)));
+      if (const char* e = getenv("RFX_GEN_PAD")) { const int v = atoi(e); if (v == 0 || (v >= 3 && v <= 8)) gg.pad_shift = v; }
+    }
   }
   RFX_ON_DEVICE(device);
   rfx_plan* pl = new rfx_plan();
@@ -294,10 +310,24 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     pl->gt.hi2 = d + 2 * kGenTwLo + gg.nhi;
     pl->gt.win = pl->d_win;
     std::vector<int> rev(gg.nc);
-    for (int k = 0; k < gg.nc; ++k) rev[k] = gen_digit_reverse(gg, k);
+    for (int k = 0; k < gg.nc; ++k) rev[k] = gen_ipad(gen_digit_reverse(gg, k), gg.pad_shift);  // LDS position incl. padding
     RFX_HIP(hipMalloc(&pl->d_gen_rev, rev.size() * sizeof(int)));
     RFX_HIP(hipMemcpy(pl->d_gen_rev, rev.data(), rev.size() * sizeof(int), hipMemcpyHostToDevice));
     pl->gt.rev = pl->d_gen_rev;
+    // exact twiddles of every pass (double precision, rounded once)
+    std::vector<cf> twt((size_t)gen_tw_table_elems(gg) + 1);
+    for (int s2 = 0, L = gg.nc; s2 < gg.nstages; ++s2) {
+      const int R = gg.radix[s2], m = L / R, off = gen_tw_table_offset(gg, s2);
+      for (int i = 0; i < m; ++i)
+        for (int q = 1; q < R; ++q) {
+          const double ang = -PI2 * (double)(((long long)i * q) % L) / (double)L;
+          twt[(size_t)off + (size_t)i * (R - 1) + q - 1] = cf{(float)cos(ang), (float)sin(ang)};
+        }
+      L = m;
+    }
+    RFX_HIP(hipMalloc(&pl->d_gen_tw, twt.size() * sizeof(cf)));
+    RFX_HIP(hipMemcpy(pl->d_gen_tw, twt.data(), twt.size() * sizeof(cf), hipMemcpyHostToDevice));
+    pl->gt.tw = pl->d_gen_tw;
   }
 
   if (h_melfb) {
@@ -583,6 +613,7 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_slot_idx);
     (void)hipFree(plan->d_gen_tables);
     (void)hipFree(plan->d_gen_rev);
+    (void)hipFree(plan->d_gen_tw);
   }
   delete plan;
   return RFX_OK;
@@ -683,21 +714,16 @@ static void gl_layout(const rfx_plan* plan, int B, int T, size_t& off_audio, siz
 // torch.istft(center=True, length=None) returns n_fft + hop*(T-1) - 2*(n_fft/2) samples: hop*(T-1), plus one when n_fft is odd
 static int gen_out_len(const GenGeom& g, int T) { return g.hop * (T - 1) + (g.n_fft & 1); }
 
-// generic path: Z and tprev spectra, the windowed frames, one audio estimate
-static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_z, size_t& off_tprev, size_t& off_frames, size_t& off_audio,
-                          size_t& total, int& Lpad) {
+// generic path: the windowed synthesis frames and three generations of the audio estimate (x_{k-1}, x_k read; x_{k+1} written)
+static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames, size_t& off_audio, size_t& total, int& Lpad) {
   const GenGeom& g = plan->gg;
   const size_t nf = (size_t)B * T;
   Lpad = (int)align_up((size_t)gen_out_len(g, T), 64);
   size_t o = 0;
-  off_z = o;
-  o += align_up(nf * g.fs * sizeof(cf), 256);
-  off_tprev = o;
-  o += align_up(nf * g.fs * sizeof(cf), 256);
   off_frames = o;
   o += align_up(nf * g.win * sizeof(float), 256);
   off_audio = o;
-  o += align_up((size_t)B * Lpad * sizeof(float), 256);
+  o += align_up(3 * (size_t)B * Lpad * sizeof(float), 256);
   total = o;
 }
 
@@ -709,50 +735,39 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   if (n_iter > 0 && L <= g.n_fft / 2)
     return fail(RFX_ERR_INVALID, "rfx_griffinlim: Padding size should be less than the corresponding input dimension (reflect padding " +
                                  std::to_string(g.n_fft / 2) + " needs more than that many samples)");
-  size_t oz, ot, ofr, oa, total;
+  size_t ofr, oa, total;
   int Lpad;
-  gen_gl_layout(plan, B, T, oz, ot, ofr, oa, total, Lpad);
+  gen_gl_layout(plan, B, T, ofr, oa, total, Lpad);
   if (workspace_bytes < total) return fail(RFX_ERR_WORKSPACE, "rfx_griffinlim: workspace too small");
   char* ws = (char*)d_workspace;
-  cf* Z = (cf*)(ws + oz);
-  cf* tprev = (cf*)(ws + ot);
   float* frames = (float*)(ws + ofr);
-  float* audio = (float*)(ws + oa);
+  float* gen[3];
+  for (int i = 0; i < 3; ++i) gen[i] = (float*)(ws + oa) + (size_t)i * B * Lpad;  // x_k lives in gen[k % 3]
   EventList events;
   if (h_launch_ms) {
     RFX_HIP(events.create(n_iter + 2));
     RFX_HIP(hipEventRecord(events.ev[0], stream));
   }
-  GenIstftArgs ia{};
-  ia.g = g;
-  ia.tb = plan->gt;
-  ia.z = Z;
-  ia.S = d_mag;
-  ia.angles0 = (const cf*)d_angles0;
-  ia.seed = seed;
-  ia.frames = frames;
-  ia.B = B;
-  ia.T = T;
-  GenStftArgs sa{};
-  sa.g = g;
-  sa.tb = plan->gt;
-  sa.wave = audio;
-  sa.wave_stride = (size_t)Lpad;
-  sa.S = d_mag;
-  sa.tprev = tprev;
-  sa.z = Z;
-  sa.mom = momentum / (1.f + momentum);
-  sa.B = B;
-  sa.T = T;
-  sa.Lw = L;
+  GenGlArgs a{};
+  a.g = g;
+  a.tb = plan->gt;
+  a.S = d_mag;
+  a.angles0 = (const cf*)d_angles0;
+  a.audio_stride = (size_t)Lpad;
+  a.frames = frames;
+  a.mom = momentum / (1.f + momentum);
+  a.seed = seed;
+  a.B = B;
+  a.T = T;
+  a.L = L;
   for (int it = 0; it <= n_iter; ++it) {
-    if (it > 0) {  // rebuilt = STFT(x_{it-1}); Z = S * normalise(rebuilt - m * tprev); tprev = rebuilt
-      sa.first = it == 1;
-      RFX_HIP(launch_gen_stft(2, sa, plan->num_cus, stream));
-    }
-    RFX_HIP(launch_gen_istft(it == 0, ia, plan->num_cus, stream));
+    // iteration `it` analyses x_{it-1} - m * x_{it-2} (the momentum term of the reference's `rebuilt - m * tprev`, applied in
+    // the time domain) and writes the frames of x_it; it == 0 synthesises the initial estimate from S * angles0
+    a.x_cur = gen[(it + 2) % 3];
+    a.x_prev = gen[(it + 1) % 3];
+    RFX_HIP(launch_gen_gl(it == 0 ? 0 : it == 1 ? 1 : 2, a, plan->num_cus, stream));
     const bool last = it == n_iter;
-    RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : audio, g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+    RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
     if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
   }
   if (h_launch_ms) {
@@ -765,9 +780,9 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
 size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
   if (!plan || B <= 0 || T < 2) return 0;
   if (plan->generic) {
-    size_t a, b, c, d, total;
+    size_t a, b, total;
     int Lpad;
-    gen_gl_layout(plan, B, T, a, b, c, d, total, Lpad);
+    gen_gl_layout(plan, B, T, a, b, total, Lpad);
     return total;
   }
   size_t a, c, fr, total;

@@ -4,13 +4,14 @@
 // The 44.1 kHz geometry of the reference's defaults runs on the specialised engine (rfx_core.h: hard-wired 40 x 21 x 21
 // factorisation, one fused launch per Griffin-Lim iteration).  Every other sample rate / window / padding the reference
 // accepts (cli.py:43 takes the rate from the input file; spectrogram_params.py:62-81) runs here: an in-place FFT over a
-// runtime radix list in LDS (rfx_gen_core.h), one workgroup per frame, and Griffin-Lim executed in
-// the reference's own op order with its spectral state in HBM:
-//     x_k     = ISTFT(Z_k)                 gen_istft_kernel (frames) + gen_fold_kernel (overlap-add / envelope)
-//     rebuilt = STFT(x_k)                  gen_stft_kernel<GL>, whose epilogue does the per-bin update
-//     Z_{k+1} = S * normalise(rebuilt - m * tprev),  tprev <- rebuilt
-// 36 B per bin and iteration (|S| 4 + tprev 8 + 8 + Z 8 + 8) plus the windowed frames.  Slower than the specialised
-// path by design (measured: 2.6-5.7x per tile), bit-reproducible (no atomics), same entry points.
+// runtime radix list in LDS (rfx_gen_core.h), one workgroup per frame.  Griffin-Lim is two launches per iteration:
+//     gen_gl_kernel    per frame: analysis of x_k - m x_{k-1} (the momentum applied in the time domain: the STFT is linear,
+//                      see rfx_gl.hip), forward passes, Z = S * a / (|a| + 1e-16) pairwise IN PLACE on the packed spectrum,
+//                      inverse passes, windowed synthesis frame -> HBM
+//     gen_fold_kernel  overlap-add of the frames and division by the window envelope -> x_{k+1}
+// No spectrum ever reaches HBM: per bin and iteration only |S| (4 B) is read, plus the windowed frames (win floats per frame
+// written and read once) and the two L2-resident audio estimates.  (Round 2 ran the reference's op order with `rebuilt`,
+// `tprev` and Z in HBM - 36 B per bin and iteration, three launches.)  Bit-reproducible (no atomics), same entry points.
 #include <hip/hip_runtime.h>
 
 #include "rfx_gen_core.h"
@@ -41,7 +42,7 @@ __device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const Ge
   GenLds l;
   l.a = reinterpret_cast<cf*>(smem);
   l.b = l.a + (RFX_GEN_INPLACE ? 0 : gen_buf_elems(g.nc));
-  l.lo = l.b + gen_buf_elems(g.nc);
+  l.lo = l.b + (RFX_GEN_INPLACE ? gen_ibuf_elems(g.nc, g.pad_shift) : gen_buf_elems(g.nc));
   l.hi = l.lo + kGenTwLo;
   l.lo2 = l.hi + g.nhi;
   l.hi2 = l.lo2 + kGenTwLo;
@@ -55,20 +56,27 @@ __device__ __forceinline__ GenLds gen_lds(char* smem, const GenGeom& g, const Ge
 }
 
 size_t gen_lds_bytes(const GenGeom& g) {
-  return sizeof(cf) * ((RFX_GEN_INPLACE ? 1 : 2) * (size_t)gen_buf_elems(g.nc) + 2 * kGenTwLo + g.nhi + g.nhi2);
+  return sizeof(cf) * ((RFX_GEN_INPLACE ? (size_t)gen_ibuf_elems(g.nc, g.pad_shift) : 2 * (size_t)gen_buf_elems(g.nc)) + 2 * kGenTwLo + g.nhi + g.nhi2);
 }
 
 // all passes of the nc-point FFT; data starts in l.a, the result's buffer is returned.  Barriers inside.
 template <bool INV, int MAXR>
-__device__ __forceinline__ cf* gen_fft(const GenGeom& g, const GenLds& l) {
+__device__ __forceinline__ cf* gen_fft(const GenGeom& g, const GenLds& l, const cf* __restrict__ tw) {
 #if RFX_GEN_INPLACE
   int L = INV ? 1 : g.nc;  // forward: blocks shrink from nc; inverse: they grow from the last radix
+  int off = INV ? gen_tw_table_elems(g) : 0;  // this pass's slice of the exact twiddle tables
   for (int i = 0; i < g.nstages; ++i) {
     const int R = g.radix[INV ? g.nstages - 1 - i : i];
-    if (INV) L *= R;
+    if (INV) {
+      L *= R;
+      off -= (L / R) * (R - 1);
+    }
     __syncthreads();
-    gen_ip_stage<INV, MAXR>(l.a, g.nc, L, R, l.lo, l.hi, (int)threadIdx.x, (int)blockDim.x);
-    if (!INV) L /= R;
+    gen_ip_stage<INV, MAXR>(l.a, g.nc, L, R, l.lo, l.hi, (int)threadIdx.x, (int)blockDim.x, g.pad_shift, tw + off);
+    if (!INV) {
+      off += (L / R) * (R - 1);
+      L /= R;
+    }
   }
   __syncthreads();
   return l.a;
@@ -89,12 +97,16 @@ __device__ __forceinline__ cf* gen_fft(const GenGeom& g, const GenLds& l) {
 }
 
 // ---- forward: frame fr of clip b is centred on sample hop*fr of the reflect-padded waveform (torch.stft center=True)
-enum GenStftMode { kGenMag = 0, kGenSpec = 1, kGenGl = 2 };
+enum GenStftMode { kGenMag = 0, kGenSpec = 1 };
 
 // (Prefetching the next frame's samples and the epilogue's |S| / tprev into register slots across the passes was tried:
 // 229 -> 245-257 ms per 64 tiles at 48 kHz - the slot arrays spill.  The simple loops below stay.)
+// (four waves per SIMD = 128 VGPRs, so that two 512-thread workgroups share a CU: without the bound the compiler took 169
+// registers for the batched butterflies and the second workgroup no longer fitted - 121 -> 182 ms per 64 tiles at 48 kHz;
+// the O(R^2) radix-11 / 13 class keeps its larger budget)
 template <int MODE, int MAXR>
-__global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
+__global__ void __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(MAXR <= 7 ? 4 : 2)))
+gen_stft_kernel(GenStftArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GenGeom& g = a.g;
   const GenLds l = gen_lds(smem, g, a.tb);
@@ -114,59 +126,178 @@ __global__ void __launch_bounds__(kGenThreads) gen_stft_kernel(GenStftArgs a) {
         const int j = i - g.left;              // position inside the window
         if (j >= 0 && j < g.win) v[e] = x[reflect_index(g.hop * t + i - half, a.Lw)] * a.tb.win[j];
       }
-      l.a[gen_pad(n)] = cf{v[0], v[1]};
+      l.a[RFX_GEN_INPLACE ? gen_ipad(n, g.pad_shift) : gen_pad(n)] = cf{v[0], v[1]};
     }
-    const cf* Z = gen_fft<false, MAXR>(g, l);
+    const cf* Z = gen_fft<false, MAXR>(g, l, a.tb.tw);
     const size_t base = (size_t)fr * g.fs;
     for (int k = threadIdx.x; k < g.fs; k += blockDim.x) {
       if (k >= g.n_stft) {  // padding of the frame stride: keep it zero
         if (MODE == kGenMag) a.mag[base + k] = 0.f;
         if (MODE == kGenSpec) a.spec[base + k] = cf{0.f, 0.f};
-        if (MODE == kGenGl) { a.tprev[base + k] = cf{0.f, 0.f}; a.z[base + k] = cf{0.f, 0.f}; }
         continue;
       }
       const cf X = gen_split_forward(g, Z, l.lo2, l.hi2, k, RFX_GEN_INPLACE ? a.tb.rev : nullptr);
       if (MODE == kGenMag) a.mag[base + k] = sqrtf(fmaf(X.re, X.re, X.im * X.im));
       if (MODE == kGenSpec) a.spec[base + k] = X;
-      if (MODE == kGenGl) {
-        const cf tp = a.first ? cf{0.f, 0.f} : a.tprev[base + k];
-        a.z[base + k] = gen_gl_update(X, tp, a.mom, a.S[base + k]);
-        a.tprev[base + k] = X;
-      }
     }
   }
 }
 
-// ---- inverse: one-sided spectrum of frame fr -> its win_length windowed samples (irfft scaling folded in)
-template <bool INIT, int MAXR>
-__global__ void __launch_bounds__(kGenThreads) gen_istft_kernel(GenIstftArgs a) {
+// ---- Griffin-Lim, one iteration for one frame per trip.  MODE 0: Z = S * angles0 (injected or drawn) -> synthesis;
+// MODE 1: analysis of x_0 (no momentum term yet); MODE 2: analysis of x_k - m x_{k-1}.
+template <int MODE, int MAXR>
+__global__ void __launch_bounds__(kGenThreads) __attribute__((amdgpu_waves_per_eu(MAXR <= 7 ? 4 : 2)))
+gen_gl_kernel(GenGlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GenGeom& g = a.g;
   const GenLds l = gen_lds(smem, g, a.tb);
   const long long nframes = (long long)a.B * a.T;
+  const int half = g.n_fft / 2;
   const float scale = 1.0f / (float)g.nc;  // even: z = IFFT_nc(Z) ; odd: x = Re IFFT_n(Z)
+  const int npairs = gen_pair_count(g);
+#ifdef RFX_GEN_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+  int nfr = 0;
+#define GSTAMP(i) do { unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define GSTAMP(i) ((void)0)
+#endif
   for (long long fr = blockIdx.x; fr < nframes; fr += gridDim.x) {
+    const int clip = (int)(fr / a.T), t = (int)(fr - (long long)clip * a.T);
     const size_t base = (size_t)fr * g.fs;
-    auto X = [&](int k) {
-      if (!INIT) return a.z[base + k];
-      const float s = a.S[base + k];
-      cf ang;
-      if (a.angles0) ang = a.angles0[base + k];
-      else ang = rand_unit_pair(a.seed, (unsigned long long)fr * g.n_stft + k);
-      return cf{s * ang.re, s * ang.im};
-    };
-    __syncthreads();
-    for (int k = threadIdx.x; k < g.nc; k += blockDim.x)
-      l.a[RFX_GEN_INPLACE ? a.tb.rev[k] : gen_pad(k)] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
-    const cf* z = gen_fft<true, MAXR>(g, l);
-    float* __restrict__ out = a.frames + (size_t)fr * g.win;
-    for (int j = threadIdx.x; j < g.win; j += blockDim.x) {
-      const int i = j + g.left;
-      const cf zz = z[gen_pad(g.even ? i >> 1 : i)];
-      const float v = (g.even && (i & 1)) ? zz.im : zz.re;
-      out[j] = v * scale * a.tb.win[j];
+    const float* __restrict__ S = a.S + base;
+    __syncthreads();  // the previous frame's output loop is done with the buffer
+    GSTAMP(0);
+    if (MODE == 0) {
+      auto X = [&](int k) {
+        cf ang;
+        if (a.angles0) ang = a.angles0[base + k];
+        else ang = rand_unit_pair(a.seed, (unsigned long long)fr * g.n_stft + k);
+        const float s = S[k];
+        return cf{s * ang.re, s * ang.im};
+      };
+      for (int k = threadIdx.x; k < g.nc; k += blockDim.x) l.a[a.tb.rev[k]] = gen_split_inverse(g, X, l.lo2, l.hi2, k);
+    } else {
+      // windowed, zero-padded frame of x_k - m x_{k-1} (reflect-padded like torch.stft center=True), packed two reals per
+      // complex when n_fft is even.  Only the elements the window covers need loads ([n_lo, n_hi): a quarter of the frame at
+      // the reference's 100 / 400 ms); the rest is zeroed.  Loads are batched - all of a batch's global loads, then its LDS
+      // stores - so that a thread waits for HBM / L2 once per batch, not once per element.
+      const float* __restrict__ xc = a.x_cur + (size_t)clip * a.audio_stride;
+      const float* __restrict__ xp = a.x_prev + (size_t)clip * a.audio_stride;
+      const int nthr = (int)blockDim.x;
+      const int per = g.even ? 2 : 1;
+      const int n_lo = g.left / per, n_hi = (g.left + g.win + per - 1) / per;
+      for (int n = threadIdx.x; n < g.nc; n += nthr)
+        if (n < n_lo || n >= n_hi) l.a[gen_ipad(n, g.pad_shift)] = cf{0.f, 0.f};
+      constexpr int UL = 5;
+      for (int n0 = n_lo + (int)threadIdx.x; n0 < n_hi; n0 += UL * nthr) {
+        float xs[UL][2], ps[UL][2], ws[UL][2];
+#pragma unroll
+        for (int u = 0; u < UL; ++u)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            xs[u][e] = ps[u][e] = ws[u][e] = 0.f;
+            const int n = n0 + u * nthr;
+            if (e < per && n < n_hi) {
+              const int i = per * n + e;  // position inside the padded frame
+              const int j = i - g.left;   // position inside the window
+              if (j >= 0 && j < g.win) {
+                const int p = reflect_index(g.hop * t + i - half, a.L);
+                xs[u][e] = xc[p];
+                if (MODE == 2) ps[u][e] = xp[p];
+                ws[u][e] = a.tb.win[j];
+              }
+            }
+          }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          const int n = n0 + u * nthr;
+          if (n < n_hi)
+            l.a[gen_ipad(n, g.pad_shift)] = cf{fmaf(-a.mom, ps[u][0], xs[u][0]) * ws[u][0], fmaf(-a.mom, ps[u][1], xs[u][1]) * ws[u][1]};
+        }
+      }
+      __syncthreads();
+      GSTAMP(1);
+      gen_fft<false, MAXR>(g, l, a.tb.tw);  // ends with a barrier; spectrum digit-reversed in l.a
+      GSTAMP(2);
+      {
+        // split / projection / merge, pairwise in place (gen_pair_compute).  Batches of UP pairs per thread: first every
+        // global load of the batch (LDS positions from the digit-reversal table, |S| from HBM), then the LDS reads that depend
+        // on them, the arithmetic, the stores - one global round trip and one LDS round trip per batch.
+        constexpr int UP = 5;
+        const int kc_of0 = g.even ? g.nc : 0;
+        for (int k0 = threadIdx.x; k0 < npairs; k0 += UP * nthr) {
+          GenPair pr[UP];
+          int pk[UP], pc[UP];
+#pragma unroll
+          for (int u = 0; u < UP; ++u) {
+            const int k = k0 + u * nthr;
+            const bool ok = k < npairs;
+            const int kk = ok ? k : 0;
+            const int kc = g.even ? g.nc - kk : (kk == 0 ? 0 : g.n_fft - kk);  // partner ELEMENT (odd n_fft: the mirror element)
+            pr[u].k = kk;
+            pk[u] = a.tb.rev[kk];
+            pc[u] = a.tb.rev[kc == kc_of0 && g.even ? 0 : kc];
+            pr[u].sk = S[kk];
+            pr[u].sc = g.even ? S[kc] : 0.f;  // even, k == 0: bin nc
+          }
+#pragma unroll
+          for (int u = 0; u < UP; ++u) {
+            pr[u].zk = l.a[pk[u]];
+            pr[u].zc = g.even ? l.a[pc[u]] : pr[u].zk;
+          }
+#pragma unroll
+          for (int u = 0; u < UP; ++u) gen_pair_compute(pr[u], g, l.lo2, l.hi2);
+#pragma unroll
+          for (int u = 0; u < UP; ++u) {
+            const int k = k0 + u * nthr;
+            if (k < npairs) {
+              l.a[pk[u]] = pr[u].zk;
+              const bool partner = g.even ? (k != 0 && k != g.nc - k) : k != 0;
+              if (partner) l.a[pc[u]] = pr[u].zc;
+            }
+          }
+        }
+      }
     }
+#ifdef RFX_GEN_TIMING
+    __syncthreads();
+#endif
+    GSTAMP(3);
+    const cf* z = gen_fft<true, MAXR>(g, l, a.tb.tw);  // starts with a barrier
+    GSTAMP(4);
+    float* __restrict__ out = a.frames + (size_t)fr * g.win;
+    {
+      constexpr int UO = 5;  // window samples fetched per batch before the stores
+      const int nthr = (int)blockDim.x;
+      for (int j0 = threadIdx.x; j0 < g.win; j0 += UO * nthr) {
+        float wv[UO], zv[UO];
+#pragma unroll
+        for (int u = 0; u < UO; ++u) {
+          const int j = j0 + u * nthr;
+          const int jj = j < g.win ? j : 0;
+          const int i = jj + g.left;
+          wv[u] = a.tb.win[jj];
+          const cf zz = z[gen_ipad(g.even ? i >> 1 : i, g.pad_shift)];
+          zv[u] = (g.even && (i & 1)) ? zz.im : zz.re;
+        }
+#pragma unroll
+        for (int u = 0; u < UO; ++u) {
+          const int j = j0 + u * nthr;
+          if (j < g.win) out[j] = zv[u] * scale * wv[u];
+        }
+      }
+    }
+    GSTAMP(5);
+#ifdef RFX_GEN_TIMING
+    ++nfr;
+#endif
   }
+#ifdef RFX_GEN_TIMING
+  if (MODE == 2 && blockIdx.x == 7 && threadIdx.x == 0)
+    printf("gen_gl timing (100 MHz ticks per frame, %d frames): barrier-wait %.1f load %.1f fwd %.1f pair %.1f inv %.1f out %.1f\n", nfr,
+           (double)tacc[0] / nfr, (double)tacc[1] / nfr, (double)tacc[2] / nfr, (double)tacc[3] / nfr, (double)tacc[4] / nfr, (double)tacc[5] / nfr);
+#endif
 }
 
 // overlap-add of the windowed frames and division by the window envelope (torch.istft center=True, length = hop*(T-1)):
@@ -241,53 +372,55 @@ __global__ void __launch_bounds__(256) gen_mel_kernel(const float* __restrict__ 
 
 // --------------------------------------------------------------------------------------------------------------------
 static int gen_grid(const GenGeom& g, int num_cus, long long nframes) {
-  // resident workgroups: LDS bound (160 KiB per CU)
+  // resident workgroups: LDS bound (160 KiB per CU) and register bound (128 VGPRs: 16 waves per CU)
   const size_t lds = gen_lds_bytes(g);
   int per_cu = (int)((160u * 1024u) / (lds + 512));
   if (per_cu < 1) per_cu = 1;
-  const int by_waves = 2048 / kGenThreads;  // 32 wave slots per CU
-  if (per_cu > by_waves) per_cu = by_waves;
+  const int by_waves = 1024 / g.nthr;
+  if (per_cu > by_waves) per_cu = by_waves < 1 ? 1 : by_waves;
   long long n = (long long)num_cus * per_cu;
   return (int)(n < nframes ? n : nframes);
 }
 
 // kernels by (mode, radix class)
 using GenStftFn = void (*)(GenStftArgs);
-using GenIstftFn = void (*)(GenIstftArgs);
+using GenGlFn = void (*)(GenGlArgs);
 template <int MAXR>
 static GenStftFn gen_stft_fn(int mode) {
-  return mode == kGenMag ? gen_stft_kernel<kGenMag, MAXR> : mode == kGenSpec ? gen_stft_kernel<kGenSpec, MAXR> : gen_stft_kernel<kGenGl, MAXR>;
+  return mode == kGenMag ? gen_stft_kernel<kGenMag, MAXR> : gen_stft_kernel<kGenSpec, MAXR>;
 }
 static GenStftFn gen_stft_fn(const GenGeom& g, int mode) {
   const int c = gen_radix_class(g.radix, g.nstages);
   return c == 5 ? gen_stft_fn<5>(mode) : c == 7 ? gen_stft_fn<7>(mode) : gen_stft_fn<13>(mode);
 }
-static GenIstftFn gen_istft_fn(const GenGeom& g, bool init) {
+template <int MAXR>
+static GenGlFn gen_gl_fn(int mode) {
+  return mode == 0 ? gen_gl_kernel<0, MAXR> : mode == 1 ? gen_gl_kernel<1, MAXR> : gen_gl_kernel<2, MAXR>;
+}
+static GenGlFn gen_gl_fn(const GenGeom& g, int mode) {
   const int c = gen_radix_class(g.radix, g.nstages);
-  if (c == 5) return init ? gen_istft_kernel<true, 5> : gen_istft_kernel<false, 5>;
-  if (c == 7) return init ? gen_istft_kernel<true, 7> : gen_istft_kernel<false, 7>;
-  return init ? gen_istft_kernel<true, 13> : gen_istft_kernel<false, 13>;
+  return c == 5 ? gen_gl_fn<5>(mode) : c == 7 ? gen_gl_fn<7>(mode) : gen_gl_fn<13>(mode);
 }
 
 hipError_t prepare_generic_kernels(const GenGeom& g) {
   const int lds = (int)gen_lds_bytes(g);
   hipError_t e;
-  for (int mode = 0; mode < 3; ++mode)
+  for (int mode = 0; mode < 2; ++mode)
     if ((e = hipFuncSetAttribute((const void*)gen_stft_fn(g, mode), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
-  for (int init = 0; init < 2; ++init)
-    if ((e = hipFuncSetAttribute((const void*)gen_istft_fn(g, init != 0), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  for (int mode = 0; mode < 3; ++mode)
+    if ((e = hipFuncSetAttribute((const void*)gen_gl_fn(g, mode), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
   return hipSuccess;
 }
 
 hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream) {
   const int grid = gen_grid(a.g, num_cus, (long long)a.B * a.T);
-  hipLaunchKernelGGL(gen_stft_fn(a.g, mode), dim3(grid), dim3(kGenThreads), gen_lds_bytes(a.g), stream, a);
+  hipLaunchKernelGGL(gen_stft_fn(a.g, mode), dim3(grid), dim3(a.g.nthr), gen_lds_bytes(a.g), stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_gen_istft(bool init, const GenIstftArgs& a, int num_cus, hipStream_t stream) {
+hipError_t launch_gen_gl(int mode, const GenGlArgs& a, int num_cus, hipStream_t stream) {
   const int grid = gen_grid(a.g, num_cus, (long long)a.B * a.T);
-  hipLaunchKernelGGL(gen_istft_fn(a.g, init), dim3(grid), dim3(kGenThreads), gen_lds_bytes(a.g), stream, a);
+  hipLaunchKernelGGL(gen_gl_fn(a.g, mode), dim3(grid), dim3(a.g.nthr), gen_lds_bytes(a.g), stream, a);
   return hipGetLastError();
 }
 

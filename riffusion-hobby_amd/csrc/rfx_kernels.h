@@ -160,7 +160,8 @@ struct GenTables {
   const cf* lo2;     // [128]   exp(-2 pi i t / n_fft)
   const cf* hi2;     // [nhi2]  exp(-2 pi i 128 t / n_fft)
   const float* win;  // [win]
-  const int* rev;    // [nc] position of element k after the in-place forward passes (digit reversal)
+  const int* rev;    // [nc] LDS position (padding included) of element k after the in-place forward passes (digit reversal)
+  const cf* tw;      // exact per-pass twiddles W_L^{i p} (gen_tw_table_offset / gen_ip_compute), all passes back to back
 };
 struct GenStftArgs {
   GenGeom g;
@@ -169,27 +170,26 @@ struct GenStftArgs {
   size_t wave_stride;
   float* mag;          // mode 0: [B*T][fs] |X|
   cf* spec;            // mode 1: [B*T][fs] X
-  const float* S;      // mode 2 (Griffin-Lim update): magnitudes
-  cf* tprev;           //         previous rebuilt spectrum, read (unless first) and replaced
-  cf* z;               //         next spectrum estimate S * angles
-  float mom;
-  int first;
   int B, T, Lw;
 };
-struct GenIstftArgs {
+// one Griffin-Lim iteration of the generic engine, frame by frame: analysis of x_k - m x_{k-1}, projection, synthesis
+struct GenGlArgs {
   GenGeom g;
   GenTables tb;
-  const cf* z;         // spectrum estimate [B*T][fs] (iterations)
-  const float* S;      // init: magnitudes ...
-  const cf* angles0;   //       ... times injected angles, or drawn from `seed` when null
+  const float* S;        // [B*T][fs] magnitudes
+  const cf* angles0;     // mode 0: optional injected initial angles [B*T][fs] (drawn from `seed` when null)
+  const float* x_cur;    // modes 1, 2: x_k      [B][audio_stride], L valid samples per clip
+  const float* x_prev;   // mode 2:     x_{k-1}
+  size_t audio_stride;
+  float* frames;         // [B*T][win] windowed, scaled synthesis frames (gen_fold_kernel overlap-adds them)
+  float mom;             // momentum / (1 + momentum)
   unsigned long long seed;
-  float* frames;       // [B*T][win] windowed, scaled frames
-  int B, T;
+  int B, T, L;
 };
 hipError_t prepare_generic_kernels(const GenGeom& g);
 size_t gen_lds_bytes(const GenGeom& g);
-hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream);  // mode 0 mag, 1 spec, 2 Griffin-Lim
-hipError_t launch_gen_istft(bool init, const GenIstftArgs& a, int num_cus, hipStream_t stream);
+hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream);  // mode 0 mag, 1 spec
+hipError_t launch_gen_gl(int mode, const GenGlArgs& a, int num_cus, hipStream_t stream);      // mode 0 init, 1 first iteration, 2 iteration
 hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
                            hipStream_t stream);  // L output samples per clip
 hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream);

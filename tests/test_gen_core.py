@@ -71,10 +71,49 @@ def test_inplace_passes_match_numpy(emu, n_fft):
     assert np.abs(back - want).max() / np.abs(want).max() < 3e-6
 
 
+@pytest.mark.parametrize("n_fft", LENGTHS)
+def test_fused_frame_update_matches_numpy(emu, n_fft):
+    """One frame of the fused Griffin-Lim kernel: rfft -> S * X / (|X| + 1e-16) -> irfft, with the projection done pairwise IN
+    PLACE on the packed, digit-reversed spectrum between the forward and the inverse passes (gen_pair_project)."""
+    rng = np.random.default_rng(n_fft + 2)
+    x = rng.standard_normal(n_fft).astype(np.float32)
+    S = (np.abs(rng.standard_normal(n_fft // 2 + 1)) * 100).astype(np.float32)
+    out = np.zeros(n_fft, np.float32)
+    assert emu.emu_gen_gl_frame(n_fft, x.ctypes.data_as(FP), S.ctypes.data_as(FP), out.ctypes.data_as(FP), 64) == 0
+    X = np.fft.rfft(x.astype(np.float64))
+    want = np.fft.irfft(S.astype(np.float64) * X / (np.abs(X) + 1e-16), n_fft)
+    assert np.abs(out - want).max() / np.abs(want).max() < 5e-6
+    out2 = np.zeros_like(out)
+    emu.emu_gen_gl_frame(n_fft, x.ctypes.data_as(FP), S.ctypes.data_as(FP), out2.ctypes.data_as(FP), 13)
+    assert np.array_equal(out, out2)  # the partition of pairs over threads does not matter
+    # LDS padding (element i at i + (i >> ps), picked per geometry against bank conflicts) moves data, not arithmetic
+    for ps in (4, 6):
+        out3 = np.zeros_like(out)
+        assert emu.emu_gen_gl_frame_padded(n_fft, x.ctypes.data_as(FP), S.ctypes.data_as(FP), out3.ctypes.data_as(FP), 64, ps, 0) == 0
+        assert np.array_equal(out, out3)
+    # the kernels' twiddles: exact per-pass tables (rounded once from double) instead of products of two table entries
+    out4 = np.zeros_like(out)
+    assert emu.emu_gen_gl_frame_padded(n_fft, x.ctypes.data_as(FP), S.ctypes.data_as(FP), out4.ctypes.data_as(FP), 64, 6, 1) == 0
+    err_exact = np.abs(out4 - want).max() / np.abs(want).max()
+    assert err_exact < 5e-6 and err_exact <= 1.25 * np.abs(out - want).max() / np.abs(want).max() + 1e-7
+
+
+def test_lds_padding_choice(emu):
+    """48 kHz: after the forward passes consecutive bins sit 600 elements apart (48 mod 64 banks: four banks for a wave);
+    with room for it the picker takes the shift that makes the stride 609 elements (2 mod 64 banks), without room none."""
+    assert emu.emu_gen_pick_pad(19200, 9600 + 200) == 6
+    assert emu.emu_gen_pick_pad(19200, 9600) == 0
+    assert emu.emu_gen_pick_pad(8820, 4410 + 400) in (0, 7)  # 22.05 kHz: the unpadded stride (294 elements) already spreads over 16 banks
+
+
 def test_factorisation_and_unsupported_lengths(emu):
     radix = np.zeros(16, np.int32)
     n = emu.emu_gen_factor(19200, radix.ctypes.data_as(IP))
-    assert n > 0 and int(np.prod(radix[:n])) == 9600 and set(radix[:n]) <= {2, 3, 4, 5, 7, 11, 13}
+    assert n > 0 and int(np.prod(radix[:n])) == 9600 and set(radix[:n]) <= {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16}
+    assert n <= 4  # composite digits: 48 kHz takes four passes ([16, 15, 10, 4]), not the seven of radices 4 / 2 / 3 / 5
+    for n_fft, most in ((n_fft_of(22050), 4), (n_fft_of(32000), 4), (n_fft_of(16000), 4), (n_fft_of(8000), 3), (3465, 4)):
+        k = emu.emu_gen_factor(n_fft, radix.ctypes.data_as(IP))
+        assert 0 < k <= most and int(np.prod(radix[:k])) == (n_fft // 2 if n_fft % 2 == 0 else n_fft)
     assert emu.emu_gen_factor(2 * 17, radix.ctypes.data_as(IP)) == 0  # prime factor 17: rejected, not mis-computed
     assert emu.emu_gen_factor(2 * 10007, radix.ctypes.data_as(IP)) == 0
 
