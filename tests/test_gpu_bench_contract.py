@@ -37,7 +37,7 @@ def test_headline_line_small_batch():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["binding"]["bound"] == "valu" and 0 < r["binding"]["frac"] < 1.2 and "source" in r["from_profiles"]
     f = d["forward"]
-    assert f["unit"] == "images/s" and f["value"] > 0 and f["roofline"]["kernel"] == "rfx::stft_mel_kernel"
+    assert f["unit"] == "images/s" and f["value"] > 0 and f["roofline"]["kernel"] == "rfx::stft_mel2_kernel" and 0 < f["roofline"]["true_flops_frac"] < 1
     assert {"image_decode_ms", "inverse_mel_ms", "griffinlim_ms", "pcm16_ms"} <= set(d["stages"])
     assert 0 < d["single_tile_latency"]["mono_ms"] < d["single_tile_latency"]["stereo_ms"] * 1.5
 
@@ -58,3 +58,4 @@ def test_sharded_stereo_workload_small():
                         "--warmup", "0"], capture_output=True, text=True, timeout=600)
     d = _one_json_line(p)
     assert d["scaling"] == "strong" and d["config"]["griffin_lim_iters"] == 64 and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert d["config"]["gather"] == "none" and {"compute_ms", "compute_plus_d2h_ms", "d2h_exposed_ms", "d2h_own_shard_raw_ms"} <= set(d["stages"])
