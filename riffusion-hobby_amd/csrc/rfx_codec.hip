@@ -78,36 +78,57 @@ __global__ void clip_max_finish_kernel(unsigned* keys, int n) {
 // q = uint8(255 - float32(pow(float32(x / max), power)) * 255): monotone non-increasing in the
 // float32 ratio r = x / max, so q = number of thresholds thr[v] (v = 0..254, descending) with
 // r < thr[v], where thr[v] is the smallest float32 r whose numpy result is <= v.
-__global__ void __launch_bounds__(256) image_encode_kernel(const float* __restrict__ mel, const float* __restrict__ clip_max,
+// One workgroup per image row (blockIdx.y = row h, blockIdx.z = clip n): no per-pixel 64-bit divisions; a thread takes four
+// consecutive pixels: one 16-byte load per channel, twelve bytes of RGB out as three dwords (the first version divided a
+// 64-bit pixel index three times per pixel and stored single bytes: 65 us per 64 tiles; now memory bound).
+__global__ void __launch_bounds__(128) image_encode_kernel(const float* __restrict__ mel, const float* __restrict__ clip_max,
                                                           const float* __restrict__ thr, uint8_t* __restrict__ img, int M,
-                                                          int T, int C, size_t total_px) {
+                                                          int T, int C) {
   __shared__ float thr_s[256];
-  thr_s[threadIdx.x] = threadIdx.x < 255 ? thr[threadIdx.x] : -__builtin_inff();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) thr_s[i] = i < 255 ? thr[i] : -__builtin_inff();
   __syncthreads();
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pixel index over (N, M, T)
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < total_px; i += stride) {
-    const int t = (int)(i % T);
-    const size_t r = i / T;
-    const int h = (int)(r % M);  // image row (already flipped: row h shows mel bin M-1-h)
-    const size_t n = r / M;
-    const float mx = clip_max[n];
-    uint8_t px[3] = {0, 0, 0};
-    for (int c = 0; c < C; ++c) {
-      const float x = mel[((n * C + c) * M + (M - 1 - h)) * T + t];
-      const float ratio = __fdiv_rn(x, mx);
-      // thr_s is descending in v: find the count of v with ratio < thr[v]  (binary search, 8 steps)
-      int lo = 0, hi = 255;  // answer in [0, 255]
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (ratio < thr_s[mid]) lo = mid + 1; else hi = mid;
-      }
-      const uint8_t q = (uint8_t)lo;
-      if (C == 1) { px[0] = px[1] = px[2] = q; } else { px[1 + c] = q; }
+  const int h = blockIdx.y;  // image row (already flipped: row h shows mel bin M-1-h)
+  const size_t n = blockIdx.z;
+  const float mx = clip_max[n];
+  auto quantise = [&](float x) {
+    const float ratio = __fdiv_rn(x, mx);
+    // thr_s is descending in v: find the count of v with ratio < thr[v]  (binary search, 8 steps)
+    int lo = 0, hi = 255;  // answer in [0, 255]
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+      const int mid = (lo + hi) >> 1;
+      if (ratio < thr_s[mid]) lo = mid + 1; else hi = mid;
     }
-    img[i * 3 + 0] = px[0];
-    img[i * 3 + 1] = px[1];
-    img[i * 3 + 2] = px[2];
+    return (unsigned)lo;
+  };
+  uint8_t* __restrict__ row_out = img + ((n * M + h) * (size_t)T) * 3;
+  const bool aligned = (T & 3) == 0;  // rows of whole 16-byte groups: vector path
+  for (int t0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x); t0 < T; t0 += 4 * gridDim.x * blockDim.x) {
+    unsigned q[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const int npx = min(4, T - t0);
+    for (int c = 0; c < C; ++c) {
+      const float* __restrict__ src = mel + ((n * C + c) * M + (M - 1 - h)) * (size_t)T + t0;
+      if (aligned) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        q[c][0] = quantise(v.x); q[c][1] = quantise(v.y); q[c][2] = quantise(v.z); q[c][3] = quantise(v.w);
+      } else {
+        for (int p = 0; p < npx; ++p) q[c][p] = quantise(src[p]);
+      }
+    }
+    unsigned char px[12];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (C == 1) { px[3 * p] = px[3 * p + 1] = px[3 * p + 2] = (unsigned char)q[0][p]; }
+      else { px[3 * p] = 0; px[3 * p + 1] = (unsigned char)q[0][p]; px[3 * p + 2] = (unsigned char)q[1][p]; }
+    }
+    if (aligned) {  // 12 bytes = three dwords at a 4-byte aligned address (3 * t0 with t0 % 4 == 0, rows of 3 T bytes with T % 4 == 0)
+      unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(row_out + 3 * (size_t)t0);
+#pragma unroll
+      for (int wd = 0; wd < 3; ++wd)
+        dst[wd] = (unsigned)px[4 * wd] | ((unsigned)px[4 * wd + 1] << 8) | ((unsigned)px[4 * wd + 2] << 16) | ((unsigned)px[4 * wd + 3] << 24);
+    } else {
+      for (int b = 0; b < 3 * npx; ++b) row_out[3 * (size_t)t0 + b] = px[b];
+    }
   }
 }
 
@@ -157,8 +178,8 @@ hipError_t launch_clip_max(const float* x, float* out, int nclips, size_t count,
 }
 hipError_t launch_image_encode(const float* mel, const float* clip_max, const float* thr, uint8_t* img, int N, int M, int T,
                                int C, hipStream_t s) {
-  const size_t total = (size_t)N * M * T;
-  hipLaunchKernelGGL(image_encode_kernel, dim3(grid_for(total)), dim3(256), 0, s, mel, clip_max, thr, img, M, T, C, total);
+  const int bx = (T + 4 * 128 - 1) / (4 * 128);
+  hipLaunchKernelGGL(image_encode_kernel, dim3(bx < 1 ? 1 : bx, M, N), dim3(128), 0, s, mel, clip_max, thr, img, M, T, C);
   return hipGetLastError();
 }
 hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s) {
