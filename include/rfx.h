@@ -35,7 +35,8 @@ typedef enum {
   RFX_ERR_INVALID = -1,     /* bad argument / unsupported geometry */
   RFX_ERR_HIP = -2,         /* a HIP runtime call failed */
   RFX_ERR_WORKSPACE = -3,   /* workspace too small */
-  RFX_ERR_UNSUPPORTED = -4  /* FFT length with a prime factor above 13 or beyond the LDS budget; non-banded filterbank */
+  RFX_ERR_UNSUPPORTED = -4  /* FFT length with a prime factor above 13 or whose frame buffer exceeds the 160 KiB of LDS (n_fft above
+                               about 39 000); non-banded filterbank */
 } rfx_status;
 
 /* Mirrors the fields of riffusion/spectrogram_params.py:21-42 that the arithmetic depends on,
@@ -56,7 +57,9 @@ int rfx_frame_stride(void);   /* of the default 44.1 kHz geometry; per plan: rfx
 int rfx_num_bins(void);
 /* frame stride of THIS plan's slot arrays (generic-geometry plans store plain bin-ordered frames, n_stft rounded up to 64) */
 int rfx_plan_frame_stride(const rfx_plan* plan);
-/* 1 when the plan runs on the generic engine (any geometry but 17640 / 4410 / 441) */
+/* 1 when the plan runs on the generic engine (any geometry but 17640 / 4410 / 441): an in-place mixed-radix FFT (digits up to 16,
+ * exact per-pass twiddles) in LDS, Griffin-Lim fused per frame with the momentum applied in the time domain - the same
+ * formulation as the specialised engine, two launches per iteration; measured 1.9-3.3x slower per tile */
 int rfx_plan_is_generic(const rfx_plan* plan);
 
 /* Builds the device constants that spectrogram_converter.py:47-99 builds as torchaudio module

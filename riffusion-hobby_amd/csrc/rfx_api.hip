@@ -215,8 +215,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     gg.nhi = gg.nc / kGenTwLo + 1;
     gg.nhi2 = gg.nc / kGenTwLo + 2;
     if (gg.nc > kGenMaxNc)
-      return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: n_fft = " + std::to_string(params->n_fft) + " needs more than the 160 KiB of LDS a "
-                  "workgroup has for its two FFT buffers (supported: n_fft <= 20000 when even, <= 10000 when odd)");
+      return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: n_fft = " + std::to_string(params->n_fft) + ": the frame's FFT buffer (" +
+                  std::to_string(gg.nc) + " complex numbers) does not fit the 160 KiB of LDS of a CU");
     gg.nthr = 512;
     if (!gen_factor(gg.nc, gg.radix, &gg.nstages))
       return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: FFT length " + std::to_string(gg.nc) + " (from n_fft = " + std::to_string(params->n_fft) +
@@ -234,6 +234,11 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       const size_t room = (160u * 1024u) / per_cu - tables - 512;
       gg.pad_shift = gen_pick_pad(gg, (int)(room / sizeof(cf)));
       if (const char* e = getenv("RFX_GEN_PAD")) { const int v = atoi(e); if (v == 0 || (v >= 3 && v <= 8)) gg.pad_shift = v; }
+      if (gen_lds_bytes(gg) > 160u * 1024u) gg.pad_shift = 0;
+      if (gen_lds_bytes(gg) > 160u * 1024u)
+        return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: n_fft = " + std::to_string(params->n_fft) + ": the frame's FFT buffer and twiddle tables (" +
+                    std::to_string(gen_lds_bytes(gg)) + " bytes) do not fit the 160 KiB of LDS of a CU (largest supported: n_fft about 39000 when "
+                    "even, 19500 when odd)");
     }
   }
   RFX_ON_DEVICE(device);

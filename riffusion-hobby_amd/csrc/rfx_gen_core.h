@@ -25,7 +25,8 @@ namespace rfx {
 
 constexpr int kGenMaxStages = 16;
 constexpr int kGenTwLo = 128;       // entries of the low twiddle table
-constexpr int kGenMaxNc = 10000;    // two LDS buffers of nc complex numbers + tables must fit 160 KiB
+constexpr int kGenMaxNc = 20000;    // hard bound on the complex FFT length; the real limit is LDS: the in-place buffer of nc complex numbers
+                                    // (+ padding) and the twiddle tables must fit the 160 KiB of a CU (checked at plan creation)
 
 // LDS position of element i of an FFT buffer.  (A pad element after every 32 - i + (i >> 5) - removes the 4- to 16-way
 // bank conflicts of the early Stockham passes, 54 % of all LDS cycles by PMC; measured: no gain at 48 kHz, 7 % slower at

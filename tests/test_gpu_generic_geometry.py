@@ -168,6 +168,8 @@ def test_unsupported_fft_length_is_refused_with_a_reason():
     assert p.n_fft == 17028
     with pytest.raises(_hip.RfxError, match="prime factor above 13"):
         _plan(p)
+    with pytest.raises(_hip.RfxError, match="does not fit the 160 KiB of LDS"):
+        _plan(_params(sample_rate=192000, max_frequency=10000))  # n_fft 76800: 38400 complex numbers = 300 KiB
 
 
 @pytest.mark.parametrize(
@@ -177,6 +179,7 @@ def test_unsupported_fft_length_is_refused_with_a_reason():
         dict(sample_rate=44100, padded_duration_ms=300, window_duration_ms=50),           # n_fft 13230 = 2 * 3^3 * 5 * 7^2, win 2205
         dict(sample_rate=34650, padded_duration_ms=100, window_duration_ms=100, max_frequency=8000),  # ODD n_fft 3465 = win
         dict(sample_rate=8000, max_frequency=4000),                                       # n_fft 3200 = 2^7 * 5^2
+        dict(sample_rate=96000),                                                          # n_fft 38400: the in-place buffer alone is 150 KiB (one workgroup per CU)
     ],
 )
 def test_other_parameter_sets_end_to_end(O, kw):
