@@ -161,6 +161,10 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
  * (mel_scale_type "slaney"), 1 = group kernel with a uniform budget (other banks whose groups fit 8 / 24 bins),
  * 0 = general LDS kernel (any banded bank), -1 = not banded (rfx_inverse_mel refuses) */
 int rfx_plan_imel_kernel(const rfx_plan* plan);
+/* 1 when that kernel (2 or 3) computes a bin's gradient in unit form, d1 + (d0 - d1) w0: valid when the two weights of every
+ * bin of the long groups sum to one, i.e. triangular filters without area normalisation (mel_scale_norm None); 0 = both
+ * weights are multiplied out (mel_scale_norm "slaney", other kernels) */
+int rfx_plan_imel_unit_form(const rfx_plan* plan);
 size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T);
 int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                     uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream);

@@ -158,6 +158,11 @@ int rfx_num_bins(void) { return kBins; }
 int rfx_plan_frame_stride(const rfx_plan* plan) { return plan ? plan->frame_stride : 0; }
 int rfx_plan_is_generic(const rfx_plan* plan) { return plan && plan->generic ? 1 : 0; }
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
+int rfx_plan_imel_unit_form(const rfx_plan* plan) {
+  if (!plan || !plan->d_melfb || !plan->imel_ok || plan->imel_variant != 0) return 0;
+  return plan->imel.fast_ok >= 2 ? plan->imel.unit_form : 0;
+}
+
 int rfx_plan_imel_kernel(const rfx_plan* plan) {
   if (!plan || !plan->d_melfb || !plan->imel_ok) return -1;
   if (plan->imel_variant == 2) return 0;
@@ -426,6 +431,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     std::vector<int> grp_start(M + 1, 0);
     bool fast = ok && M <= 512;
     int fast_code = 0;
+    bool unit_form = false;
     if (fast) {
       int prev = 0;
       for (int f = f_lo; f < f_hi && fast; ++f) {
@@ -452,6 +458,15 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
         // per-wave budgets of imel_group_kernel_perwave (rfx_kernels.h): the default bank's exact set, then the wide set
         fast_code = fits(rfx::kImelLoCap, rfx::kImelHiCap) ? 2 : fits(rfx::kImelLoCapWide, rfx::kImelHiCapWide) ? 3 : fits(uni_lo, uni_hi) ? 1 : 0;
         fast = fast_code != 0;
+        // unit form of the gradient (rfx_imel.hip): the long groups M-256 .. M-1 must have w0 + w1 == 1 per bin (triangular
+        // filters, no area normalisation), the last one w1 == 0 throughout (there is no filter M)
+        unit_form = fast_code >= 2;
+        for (int f = f_lo; f < f_hi && unit_form; ++f) {
+          const int g2 = bin_m0[f];
+          if (g2 < M - 256) continue;
+          if (g2 == M - 1) unit_form = bin_w1[f] == 0.f;
+          else unit_form = fabsf(bin_w0[f] + bin_w1[f] - 1.f) <= 1e-6f;
+        }
       }
     }
     pl->imel_ok = ok;
@@ -590,6 +605,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->imel.bin_pos2 = (const int*)(d + o_p2);
       pl->imel.grp_start = (const int*)(d + o_gs);
       pl->imel.fast_ok = fast ? fast_code : 0;
+      pl->imel.unit_form = fast && unit_form ? 1 : 0;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;

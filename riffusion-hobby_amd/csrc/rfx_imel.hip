@@ -216,14 +216,43 @@ __device__ __forceinline__ float wave_sum(float x) {
 // [max_iter][4]
 RFX_HD size_t imel_group_lds_bytes(int M, int max_iter) { return sizeof(float) * (size_t)(4 * (M + 4) + 4 * max_iter); }
 
-template <int N>
+// Two things keep the per-bin cost of a step at five instructions for the long groups (seven in round 2):
+//  * scaled state: spec, buf and the mel targets are held multiplied by kImelScale = 2^-60.  Every operation of the step
+//    is linear except the clamp at zero, and a power-of-two factor commutes with fp32 rounding, so the scaled iteration is
+//    the unscaled one bit for bit (as long as nothing leaves the normal range: values below 1.4e-20 in the reference's units
+//    would, they sit 23+ orders of magnitude under a spectrogram's scale) - and `max(0, x)` becomes the VALU's free output
+//    clamp to [0, 1] on the FMA that produces x (the upper bound is 1.15e18 in the reference's units);
+//  * unit form (UF): between two filter centres the falling weight of filter g and the rising weight of filter g+1 sum to
+//    one (torchaudio's melscale_fbanks, norm=None; checked to 1e-6 per bin at plan creation), so the gradient
+//    d0 w0 + d1 w1 = d1 + (d0 - d1) w0: one FMA per bin less, and momentum folds into the first (`fma(mom, buf, d1)`).
+//    The sums A and B keep both weights (a thread's unused register slots carry w0 = w1 = 0 and must stay out of them; their
+//    spec values drift inside [0, 1] and touch nothing).  Emulated on the CPU against the oracle the two forms sit at the
+//    same distance (rel-L2 2.1e-7 both).
+constexpr float kImelScale = 8.673617379884035e-19f;    // 2^-60
+constexpr float kImelUnscale = 1152921504606846976.0f;  // 2^60
+#ifndef RFX_IMEL_CLAMP
+#define RFX_IMEL_CLAMP 1
+#endif
+#ifndef RFX_IMEL_UFORM
+#define RFX_IMEL_UFORM 1
+#endif
+
+__device__ __forceinline__ float clamp_step(float x) {
+#if RFX_IMEL_CLAMP
+  return __builtin_amdgcn_fmed3f(x, 0.f, 1.f);  // folds into the producing instruction's clamp modifier
+#else
+  return fmaxf(0.f, x);
+#endif
+}
+
+template <int N, bool UF>
 struct GroupState {
   float spec[N], buf[N], w0[N], w1[N];
   int f0, n;  // first bin, bin count
 };
 
-template <int N>
-__device__ __forceinline__ void group_load(GroupState<N>& g, int grp, const ImelArgs& a, int frame, unsigned long long rbase) {
+template <int N, bool UF>
+__device__ __forceinline__ void group_load(GroupState<N, UF>& g, int grp, const ImelArgs& a, int frame, unsigned long long rbase, float scale) {
   const ImelTables& tb = a.tb;
   g.f0 = grp >= 0 ? tb.grp_start[grp] : 0;
   g.n = grp >= 0 ? tb.grp_start[grp + 1] - g.f0 : 0;
@@ -233,12 +262,12 @@ __device__ __forceinline__ void group_load(GroupState<N>& g, int grp, const Imel
     const int f = g.f0 + (ok ? i : 0);
     g.w0[i] = ok ? tb.bin_w0[f] : 0.f;
     g.w1[i] = ok ? tb.bin_w1[f] : 0.f;
-    g.spec[i] = ok ? (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(a.seed, rbase + f)) : 0.f;
+    g.spec[i] = ok ? scale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(a.seed, rbase + f)) : 0.f;
     g.buf[i] = 0.f;
   }
 }
-template <int N>
-__device__ __forceinline__ void group_ab(const GroupState<N>& g, float& A, float& B) {
+template <int N, bool UF>
+__device__ __forceinline__ void group_ab(const GroupState<N, UF>& g, float& A, float& B) {
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
 #pragma unroll
   for (int i = 0; i < N; i += 2) {
@@ -252,29 +281,37 @@ __device__ __forceinline__ void group_ab(const GroupState<N>& g, float& A, float
   A = a0 + a1;
   B = b0 + b1;
 }
-template <int N>
-__device__ __forceinline__ void group_step(GroupState<N>& g, float d0, float d1, float mom, float lr) {
+template <int N, bool UF>
+__device__ __forceinline__ void group_step(GroupState<N, UF>& g, float d0, float d1, float mom, float lrg) {
+  const float dd = d0 - d1;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     // torch.optim.SGD: buf.mul_(momentum).add_(grad); accumulating in place keeps buf in its register
     // (a separate gradient temporary costs a v_mov per bin and step across the loop back-edge).  The first step's
     // buf = grad needs no special case: buf starts at +0 and momentum * 0 is +0
-    float bnew = mom * g.buf[i];
-    bnew = fmaf(d0, g.w0[i], bnew);
-    bnew = fmaf(d1, g.w1[i], bnew);
+    float bnew;
+    if (UF) {
+      bnew = fmaf(mom, g.buf[i], d1);
+      bnew = fmaf(dd, g.w0[i], bnew);
+    } else {
+      bnew = mom * g.buf[i];
+      bnew = fmaf(d0, g.w0[i], bnew);
+      bnew = fmaf(d1, g.w1[i], bnew);
+    }
     g.buf[i] = bnew;
-    g.spec[i] = fmaxf(0.f, fmaf(-lr, bnew, g.spec[i]));
+    g.spec[i] = clamp_step(fmaf(-lrg, bnew, g.spec[i]));
   }
 }
-template <int N>
-__device__ __forceinline__ void group_store(const GroupState<N>& g, const ImelTables& tb, float* out) {
+template <int N, bool UF>
+__device__ __forceinline__ void group_store(const GroupState<N, UF>& g, const ImelTables& tb, float* out, float unscale) {
 #pragma unroll
   for (int i = 0; i < N; ++i)
     if (i < g.n) {
       const int f = g.f0 + i;
-      out[tb.bin_pos[f]] = g.spec[i];
+      const float v = unscale * g.spec[i];
+      out[tb.bin_pos[f]] = v;
       const int p2 = tb.bin_pos2[f];
-      if (p2 >= 0) out[p2] = g.spec[i];
+      if (p2 >= 0) out[p2] = v;
     }
 }
 
@@ -282,7 +319,7 @@ __device__ __forceinline__ void group_store(const GroupState<N>& g, const ImelTa
 // index: the kernels below deal the four classes to the waves of a workgroup in different orders.  `frame` is the frame
 // this wave's workgroup slot works on, `live` false for a slot past the last frame (it runs the same barriers on a copy of
 // the last frame's data and stores nothing).
-template <int NLO, int NHI>
+template <int NLO, int NHI, bool UF>
 __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, int tid, int frame, bool live) {
   const ImelTables& tb = a.tb;
   const int M = a.M;
@@ -298,19 +335,25 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
 
   const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;           // long groups, counted down from the top
   const int gL = (tid < M - kImelThreads) ? tid : -1;             // short groups, counted up from 0
-  GroupState<NLO> lo;
-  GroupState<NHI> hi;
-  group_load(lo, gL, a, frame, rbase);
-  group_load(hi, gH, a, frame, rbase);
-  auto melat = [&](int m) { return (m >= 0 && m < M) ? a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
+  // the short groups keep both weights (the lowest bins sit below the first filter's centre and feed one filter only);
+  // the long groups run in unit form when the plan found the bank fit for it (UF)
+  constexpr float kScale = RFX_IMEL_CLAMP ? kImelScale : 1.f, kUnscale = RFX_IMEL_CLAMP ? kImelUnscale : 1.f;
+  GroupState<NLO, false> lo;
+  GroupState<NHI, UF> hi;
+  group_load(lo, gL, a, frame, rbase, kScale);
+  group_load(hi, gH, a, frame, rbase, kScale);
+  auto melat = [&](int m) { return (m >= 0 && m < M) ? kScale * a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
   const float mL0 = gL >= 0 ? melat(gL) : 0.f, mL1 = gL >= 0 ? melat(gL + 1) : 0.f;
   const float mH0 = gH >= 0 ? melat(gH) : 0.f, mH1 = gH >= 0 ? melat(gH + 1) : 0.f;
   for (int i = tid; i < 4 * (M + 4); i += kImelThreads) Ab[i] = 0.f;  // Ab and Bb are contiguous: zero both incl. pads
-  const float gscale = -2.0f / (float)(a.C * a.T);
+  // The momentum buffer is kept in units of the gradient scale g = -2/(C T) of the loss mean (buf = g buf''): the step
+  // spec -= lr buf becomes spec = fma(-lr g, buf'', spec) and the four products g * residual per step disappear
+  const float lrg = a.lr * (-2.0f / (float)(a.C * a.T));
   // an absent group (n_mels < 512) publishes zeros to the dump entry and reads the pads around it: the loop below has no
   // branches, and the four neighbour reads of a step go out together (one LDS round trip, not four)
   const int xL = (gL >= 0 ? gL : M + 1) + 1, xH = (gH >= 0 ? gH : M + 1) + 1;
-  const bool okL = gL >= 0, okH = gH >= 0;
+  // unit form: the last group's second filter does not exist (its bins carry w1 == 0 in the bank): its residual is forced to 0
+  const bool noH1 = UF && gH == M - 1;
   const int wave = tid >> 6;
   __syncthreads();
 
@@ -323,16 +366,19 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
     Ap[xH] = AH; Bp[xH] = BH;
     __syncthreads();
     const float bLm = Bp[xL - 1], aLp = Ap[xL + 1], bHm = Bp[xH - 1], aHp = Ap[xH + 1];
-    // residuals of the two filters each group feeds: d0 = diff[g], d1 = diff[g+1]
-    const float dL0 = okL ? mL0 - AL - bLm : 0.f;
-    const float dL1 = okL ? mL1 - aLp - BL : 0.f;
-    const float dH0 = okH ? mH0 - AH - bHm : 0.f;
-    const float dH1 = okH ? mH1 - aHp - BH : 0.f;
-    const float sq = wave_sum(fmaf(dL0, dL0, dH0 * dH0));  // every filter's residual is owned exactly once
+    // residuals of the two filters each group feeds: d0 = diff[g], d1 = diff[g+1].  An absent group needs no special case:
+    // its targets and sums are zero and the entries next to the dump are never written
+    const float dL0 = mL0 - AL - bLm;
+    const float dL1 = mL1 - aLp - BL;
+    const float dH0 = mH0 - AH - bHm;
+    const float dH1 = noH1 ? 0.f : mH1 - aHp - BH;
+    // every filter's residual is owned exactly once; the loss history is kept in the reference's units
+    const float uL = kUnscale * dL0, uH = kUnscale * dH0;
+    const float sq = wave_sum(fmaf(uL, uL, uH * uH));
     if ((tid & 63) == 0) part[4 * it + wave] = sq;
-    // the last filter has no successor: its d1 multiplies w1 == 0
-    group_step(lo, gscale * dL0, gscale * dL1, a.momentum, a.lr);
-    group_step(hi, gscale * dH0, gscale * dH1, a.momentum, a.lr);
+    // (without the unit form the last filter needs nothing either: it has no successor and its d1 multiplies w1 == 0)
+    group_step(lo, dL0, dL1, a.momentum, lrg);
+    group_step(hi, dH0, dH1, a.momentum, lrg);
   };
   float* const A0 = Ab, * const A1 = Ab + (M + 4), * const B0 = Bb, * const B1 = Bb + (M + 4);
   int it = 0;
@@ -345,8 +391,8 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
 
   if (!live) return;
   float* out = a.out_slots + (size_t)frame * a.out_stride;
-  group_store(lo, tb, out);
-  group_store(hi, tb, out);
+  group_store(lo, tb, out, kUnscale);
+  group_store(hi, tb, out, kUnscale);
   for (int f = tid; f < a.n_stft; f += kImelThreads) {
     if (f >= tb.f_lo && f < tb.f_hi) continue;
     const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(a.seed, rbase + f);
@@ -371,7 +417,7 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
 template <int NLO, int NHI>
 __global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  imel_group_body<NLO, NHI>(a, smem, threadIdx.x, blockIdx.x, true);
+  imel_group_body<NLO, NHI, false>(a, smem, threadIdx.x, blockIdx.x, true);
 }
 // Group sizes fall with the role index (mel spacing is logarithmic): roles 64c..64c+63 form size class c, and each wave
 // runs the body compiled for its class's maximum, so the long-group class no longer sets everybody's instruction count.
@@ -381,14 +427,21 @@ __global__ void __launch_bounds__(kImelThreads) imel_group_kernel(ImelArgs a) {
 // (profiles/r01_wave_placement_ubench.txt: wave i and wave i+4 share a SIMD), and a class-0 wave issues 25/15 of a class-3
 // wave's instructions per SGD step.  With one frame per workgroup, which SIMD gets the heavy wave is left to the order
 // workgroups happen to arrive in; with FPW = 2 or 4 the classes are dealt so that the waves sharing a SIMD carry different
-// classes (FPW = 2: c and 3-c, FPW = 4: a Latin square, every SIMD gets one wave of each class).
+// classes (FPW = 2: c and 3-c, FPW = 4: a Latin square, every SIMD gets one wave of each class).  Measured (rounds 2, 3): one
+// frame per workgroup wins; dealing its classes by HW_REG_HW_ID (class = (SIMD + wave slot) mod 4, a Latin square over the
+// resident workgroups) or by blockIdx changes nothing (4.92 - 5.02 ms either way: the dispatcher already spreads the heavy
+// waves), and s_setprio by class costs 7 %.
 #ifndef RFX_IMEL_WAVES_PER_EU
 #define RFX_IMEL_WAVES_PER_EU 4  // 128 VGPRs: 16 waves per CU (7.6 ms vs 8.6 ms at 3, measured)
+#endif
+#ifndef RFX_IMEL_WAVES_PER_EU_UF
+#define RFX_IMEL_WAVES_PER_EU_UF 4
 #endif
 #ifndef RFX_IMEL_FPW
 #define RFX_IMEL_FPW 1
 #endif
-template <int FPW, int WPE, int L0, int H0, int L1, int H1, int L2, int H2, int L3, int H3>
+
+template <int FPW, int WPE, bool UF, int L0, int H0, int L1, int H1, int L2, int H2, int L3, int H3>
 __global__ void __launch_bounds__(kImelThreads * FPW) __attribute__((amdgpu_waves_per_eu(WPE)))
 imel_group_kernel_perwave(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -402,10 +455,10 @@ imel_group_kernel_perwave(ImelArgs a) {
   if (!live) frame = nframes - 1;
   char* my = smem + (size_t)slot * imel_group_lds_bytes(a.M, a.max_iter);
   switch (cls) {
-    case 0: imel_group_body<L0, H0>(a, my, tid, frame, live); break;
-    case 1: imel_group_body<L1, H1>(a, my, tid, frame, live); break;
-    case 2: imel_group_body<L2, H2>(a, my, tid, frame, live); break;
-    default: imel_group_body<L3, H3>(a, my, tid, frame, live); break;
+    case 0: imel_group_body<L0, H0, UF>(a, my, tid, frame, live); break;
+    case 1: imel_group_body<L1, H1, UF>(a, my, tid, frame, live); break;
+    case 2: imel_group_body<L2, H2, UF>(a, my, tid, frame, live); break;
+    default: imel_group_body<L3, H3, UF>(a, my, tid, frame, live); break;
   }
 }
 
@@ -452,15 +505,15 @@ __global__ void __launch_bounds__(1024) imel_scan_kernel(const float* __restrict
   }
 }
 
-template <int FPW, int SET>
+template <int FPW, int SET, bool UF>
 static void launch_perwave(const ImelArgs& a, hipStream_t stream) {
   const int nframes = a.B * a.T;
   const size_t lds = FPW * imel_group_lds_bytes(a.M, a.max_iter);
   constexpr const int* lo = SET == 0 ? kImelLoCap : kImelLoCapWide;
   constexpr const int* hi = SET == 0 ? kImelHiCap : kImelHiCapWide;
   // the wide set's class 0 holds 31 bins per thread (124 state registers): three waves per SIMD (168 VGPRs) instead of four
-  constexpr int wpe = SET == 0 ? RFX_IMEL_WAVES_PER_EU : 3;
-  hipLaunchKernelGGL((imel_group_kernel_perwave<FPW, wpe, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]>), dim3((nframes + FPW - 1) / FPW),
+  constexpr int wpe = SET == 0 ? (UF ? RFX_IMEL_WAVES_PER_EU_UF : RFX_IMEL_WAVES_PER_EU) : 3;
+  hipLaunchKernelGGL((imel_group_kernel_perwave<FPW, wpe, UF, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]>), dim3((nframes + FPW - 1) / FPW),
                      dim3(kImelThreads * FPW), lds, stream, a);
 }
 
@@ -469,9 +522,17 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
     // the fix-up pass runs a different number of steps (and barriers) per clip: one frame per workgroup there
     const bool fixup = a.it_limit != nullptr;
     if (a.tb.fast_ok == 2 && variant != 1) {
-      if (fixup) launch_perwave<1, 0>(a, stream); else launch_perwave<RFX_IMEL_FPW, 0>(a, stream);
+      if (a.tb.unit_form && RFX_IMEL_UFORM) {
+        if (fixup) launch_perwave<1, 0, true>(a, stream); else launch_perwave<RFX_IMEL_FPW, 0, true>(a, stream);
+      } else {
+        if (fixup) launch_perwave<1, 0, false>(a, stream); else launch_perwave<RFX_IMEL_FPW, 0, false>(a, stream);
+      }
     } else if (a.tb.fast_ok == 3 && variant != 1) {
-      if (fixup) launch_perwave<1, 1>(a, stream); else launch_perwave<RFX_IMEL_FPW, 1>(a, stream);
+      if (a.tb.unit_form && RFX_IMEL_UFORM) {
+        if (fixup) launch_perwave<1, 1, true>(a, stream); else launch_perwave<RFX_IMEL_FPW, 1, true>(a, stream);
+      } else {
+        if (fixup) launch_perwave<1, 1, false>(a, stream); else launch_perwave<RFX_IMEL_FPW, 1, false>(a, stream);
+      }
     } else {
       hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), imel_group_lds_bytes(a.M, a.max_iter), stream, a);
     }

@@ -132,6 +132,8 @@ struct ImelTables {
   int nnz;
   int fast_ok;           // 0: general kernel; 1: group formulation with <8, 24> bins per thread; 2: per-wave budgets (default set) fit too;
                          // 3: only the wide per-wave set fits
+  int unit_form;         // 1: in every long group (the top 256) a bin's two weights sum to one (to 1e-6) - the last group, whose second
+                         // filter does not exist, carries w1 == 0: the per-wave kernels compute the gradient as d1 + (d0 - d1) w0
 };
 struct ImelArgs {
   ImelTables tb;

@@ -71,6 +71,7 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_griffinlim_form": (c_int, [c_void_p, c_int, c_int]),
     "rfx_stft_frames": (c_int, [c_void_p, c_int]),
     "rfx_plan_imel_kernel": (c_int, [c_void_p]),
+    "rfx_plan_imel_unit_form": (c_int, [c_void_p]),
     "rfx_plan_destroy": (c_int, [c_void_p]),
     "rfx_pack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rfx_pack_complex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -110,6 +110,9 @@ def test_slaney_scale_and_norm(O, scale, norm, kernel):
     assert torch.equal(plan.melfb, O.mel_filterbank(op))
     which = plan.lib.rfx_plan_imel_kernel(plan.handle)
     assert which >= 0 and (kernel is None or which == kernel)
+    # the gradient's unit form needs w0 + w1 == 1 per bin: true of the triangles, not of area-normalised ones
+    unit = plan.lib.rfx_plan_imel_unit_form(plan.handle)
+    assert unit == (1 if norm is None and which >= 2 else 0)
     T = 48
     wave = synthetic_wave(2, 441 * (T - 1), seed=5)
     mel_ref = O.mel_amplitudes_from_waveform(wave, op)
@@ -128,7 +131,7 @@ def test_slaney_scale_and_norm(O, scale, norm, kernel):
     act = _active_rows(O, op)
     rel = float(torch.linalg.norm(got[:, act] - want[:, act]) / torch.linalg.norm(want[:, act]))
     print(f"mel_scale_type={scale!r} mel_scale_norm={norm!r}: forward rel-L2 {rel_fwd:.2e}, InverseMelScale-60 rel-L2 {rel:.2e}, "
-          f"SGD kernel {which} (2 = per-wave groups, 1 = uniform groups, 0 = general)")
+          f"SGD kernel {which} (2 = per-wave groups, 1 = uniform groups, 0 = general), unit-form gradient {unit}")
     assert rel <= 1e-3 and torch.equal(got[:, ~act], want[:, ~act])
 
 

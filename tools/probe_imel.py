@@ -1,5 +1,5 @@
-"""Timing probe of the InverseMelScale kernel on B synthetic mono tiles."""
-import os, sys, time
+"""Timing probe of the InverseMelScale kernel on B synthetic mono tiles (torch events on the launch stream)."""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "riffusion-hobby_amd"))
 import torch
@@ -8,8 +8,12 @@ from riffusion.spectrogram_params import SpectrogramParams
 B = int(os.environ.get("B", 64)); T = 512
 plan = _hip.get_plan(SpectrogramParams(), "cuda")
 mel = torch.rand(B, 512, T, device="cuda") ** 4 * 3e7
-for rep in range(5):
-    torch.cuda.synchronize(); t = time.time()
+ts = []
+for rep in range(14):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     out = plan.inverse_mel(mel, 1, seed=rep)
-    torch.cuda.synchronize(); dt = time.time() - t
-    print(f"inverse_mel B={B}: {dt*1e3:.1f} ms  ({B/dt:.0f} tiles/s)  finite={bool(torch.isfinite(out).all())}")
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+ts = sorted(ts[2:])
+print(f"inverse_mel B={B}: min {ts[0]:.2f} ms, median {ts[len(ts)//2]:.2f} ms  ({B/ts[len(ts)//2]*1e3:.0f} tiles/s)  finite={bool(torch.isfinite(out).all())}")
