@@ -77,17 +77,27 @@ typedef enum {
   RFX_GL_FORM_FRAMES = 2  /* always the per-frame kernel + fold (two launches per iteration) */
 } rfx_gl_form;
 
+/* Which frame engine Griffin-Lim runs on for geometries other than 17640 / 4410 / 441 */
+typedef enum {
+  RFX_ENGINE_AUTO = 0,    /* the row-family kernels where n_fft = 40 h and win_length = 10 h with h in {80, 160, 240, 320, 441, 480}
+                             (the default 400 / 100 ms at 8, 16, 24, 32, 44.1, 48 kHz; any hop), the generic FFT engine otherwise */
+  RFX_ENGINE_GENERIC = 1  /* always the generic FFT engine (cross-checks) */
+} rfx_frame_engine;
+
 /* Plan-creation options.  Set struct_size = sizeof(rfx_plan_options); zero in every other field means "default". */
 typedef struct {
   uint32_t struct_size;
   int32_t gl_form;             /* rfx_gl_form */
   int32_t gl_frames_per_slot;  /* RFX_GL_FORM_AUTO takes the per-frame form up to this many frames per resident
                                   workgroup slot of the chip (0 = default, 4: the measured crossover, 8 tiles per call) */
+  int32_t frame_engine;        /* rfx_frame_engine */
 } rfx_plan_options;
 
 /* rfx_plan_create with options (NULL = defaults = rfx_plan_create). */
 int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
                        const rfx_plan_options* options, rfx_plan** out_plan);
+/* the engine rfx_griffinlim runs on for this plan: 0 = specialised (17640 / 4410 / 441), 1 = generic FFT engine, 2 = row family */
+int rfx_plan_griffinlim_engine(const rfx_plan* plan);
 /* the form (RFX_GL_FORM_RUNS / _FRAMES) an rfx_griffinlim call of B x T frames takes on this plan */
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
 /* frames torch.stft(center=True, pad_mode="reflect") makes of Lw samples: 1 + (Lw + 2*(n_fft/2) - n_fft) / hop, i.e.

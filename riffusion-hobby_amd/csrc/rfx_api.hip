@@ -129,6 +129,12 @@ struct rfx_plan {
   int* d_gen_rev = nullptr;
   cf* d_gen_tw = nullptr;
   int frame_stride = kFrameStride;
+  // row-family Griffin-Lim (rfx_fam.hip) on top of a generic plan: n_fft = 40 h, win_length = 10 h
+  bool fam_ok = false;
+  FamGeom fam{};
+  cf* d_fam_tw = nullptr;      // [21][h] g(n')^k1, then [rb][ra-1] W_h^{i p}
+  int* d_fam_binof = nullptr;  // [fsf] bin held by each position of the slot-ordered magnitudes (-1: padding)
+  int fam_wgs_per_cu = 1;
 };
 
 namespace rfx {
@@ -157,6 +163,7 @@ int rfx_frame_stride(void) { return kFrameStride; }
 int rfx_num_bins(void) { return kBins; }
 int rfx_plan_frame_stride(const rfx_plan* plan) { return plan ? plan->frame_stride : 0; }
 int rfx_plan_is_generic(const rfx_plan* plan) { return plan && plan->generic ? 1 : 0; }
+int rfx_plan_griffinlim_engine(const rfx_plan* plan) { return !plan ? -1 : !plan->generic ? 0 : plan->fam_ok ? 2 : 1; }
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
 int rfx_plan_imel_unit_form(const rfx_plan* plan) {
   if (!plan || !plan->d_melfb || !plan->imel_ok || plan->imel_variant != 0) return 0;
@@ -201,6 +208,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     memcpy(&opt, options, options->struct_size);
     if (opt.gl_form < RFX_GL_FORM_AUTO || opt.gl_form > RFX_GL_FORM_FRAMES || opt.gl_frames_per_slot < 0)
       return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: gl_form must be RFX_GL_FORM_AUTO / _RUNS / _FRAMES, gl_frames_per_slot >= 0");
+    if (opt.frame_engine < RFX_ENGINE_AUTO || opt.frame_engine > RFX_ENGINE_GENERIC)
+      return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: frame_engine must be RFX_ENGINE_AUTO or RFX_ENGINE_GENERIC");
   }
   const bool generic = params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop ||
                        getenv("RFX_FORCE_GENERIC") != nullptr;
@@ -246,6 +255,23 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
                     "even, 19500 when odd)");
     }
   }
+  // Griffin-Lim of the geometries with n_fft = 40 h, win_length = 10 h (the default 400 / 100 ms at 48 / 32 / 24 / 16 / 8 kHz)
+  // runs on the row-family kernels; the generic engine keeps everything else of the plan (layouts, forward path)
+  FamGeom fam{};
+  bool fam_ok = generic && opt.frame_engine != RFX_ENGINE_GENERIC && getenv("RFX_NO_FAMILY") == nullptr &&
+                fam_make_geom(params->n_fft, params->win_length, params->hop_length, &fam);
+  if (fam_ok) {
+    // pad the rows by up to seven elements (bank spread of the row-to-row accesses) as long as that costs no resident workgroup
+    const size_t plain = fam_lds_bytes(fam);
+    int per_cu = (int)((160u * 1024u) / plain);
+    if (per_cu > 1024 / fam.nthr) per_cu = 1024 / fam.nthr;
+    if (per_cu < 1) fam_ok = false;
+    for (int pad = 7; fam_ok && pad > 0; --pad) {
+      FamGeom t = fam;
+      t.rs = fam.h + pad;
+      if (fam_lds_bytes(t) * per_cu <= 160u * 1024u) { fam = t; break; }
+    }
+  }
   RFX_ON_DEVICE(device);
   rfx_plan* pl = new rfx_plan();
   struct Guard {  // releases the half-built plan if any step below fails
@@ -266,6 +292,12 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   // once, never on the hot calls
   RFX_HIP(prepare_frame_kernels());
   if (generic) RFX_HIP(prepare_generic_kernels(gg));
+  if (fam_ok) {
+    RFX_HIP(prepare_fam_kernels(fam));
+    pl->fam = fam;
+    pl->fam_wgs_per_cu = fam_blocks_per_cu(fam);
+    if (const char* e = getenv("RFX_FAM_WGS_PER_CU")) pl->fam_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
+  }
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
   if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
   pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : 0;
@@ -338,6 +370,30 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     RFX_HIP(hipMalloc(&pl->d_gen_tw, twt.size() * sizeof(cf)));
     RFX_HIP(hipMemcpy(pl->d_gen_tw, twt.data(), twt.size() * sizeof(cf), hipMemcpyHostToDevice));
     pl->gt.tw = pl->d_gen_tw;
+  }
+  if (fam_ok) {
+    const FamGeom& f = pl->fam;
+    std::vector<cf> tw((size_t)kFamRows * f.h + (size_t)f.rb * (f.ra - 1));
+    for (int k1 = 0; k1 < kFamRows; ++k1)
+      for (int n = 0; n < f.h; ++n) {
+        const long long e = ((long long)k1 * (n + 15 * f.h)) % f.n_fft;
+        tw[(size_t)k1 * f.h + n] = cf{(float)cos(PI2 * (double)e / f.n_fft), (float)(-sin(PI2 * (double)e / f.n_fft))};
+      }
+    cf* twa = tw.data() + (size_t)kFamRows * f.h;
+    for (int i = 0; i < f.rb; ++i)
+      for (int q = 1; q < f.ra; ++q) {
+        const int e = (i * q) % f.h;
+        twa[(size_t)i * (f.ra - 1) + q - 1] = cf{(float)cos(PI2 * e / (double)f.h), (float)(-sin(PI2 * e / (double)f.h))};
+      }
+    RFX_HIP(hipMalloc(&pl->d_fam_tw, tw.size() * sizeof(cf)));
+    RFX_HIP(hipMemcpy(pl->d_fam_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+    std::vector<int> binof((size_t)f.fsf, -1);
+    for (int k1 = 0; k1 < kFamRows; ++k1)
+      for (int q = 0; q < f.ra; ++q)
+        for (int s2 = 0; s2 < f.rb; ++s2) binof[(size_t)s2 * f.nthr + k1 * f.ra + q] = fam_slot_bin(f, k1, q, s2, nullptr);
+    RFX_HIP(hipMalloc(&pl->d_fam_binof, binof.size() * sizeof(int)));
+    RFX_HIP(hipMemcpy(pl->d_fam_binof, binof.data(), binof.size() * sizeof(int), hipMemcpyHostToDevice));
+    pl->fam_ok = true;
   }
 
   if (h_melfb) {
@@ -627,6 +683,8 @@ int rfx_plan_destroy(rfx_plan* plan) {
     (void)hipFree(plan->d_melfb_slots);
     (void)hipFree(plan->d_kblocks);
     (void)hipFree(plan->d_imel_blob);
+    (void)hipFree(plan->d_fam_tw);
+    (void)hipFree(plan->d_fam_binof);
     (void)hipFree(plan->d_band_wt);
     (void)hipFree(plan->d_band_lo);
     (void)hipFree(plan->d_band_addr);
@@ -736,6 +794,7 @@ static void gl_layout(const rfx_plan* plan, int B, int T, size_t& off_audio, siz
 static int gen_out_len(const GenGeom& g, int T) { return g.hop * (T - 1) + (g.n_fft & 1); }
 
 // generic path: the windowed synthesis frames and three generations of the audio estimate (x_{k-1}, x_k read; x_{k+1} written)
+// (row family: plus the magnitudes re-ordered into slot order, at the end)
 static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames, size_t& off_audio, size_t& total, int& Lpad) {
   const GenGeom& g = plan->gg;
   const size_t nf = (size_t)B * T;
@@ -745,6 +804,7 @@ static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames
   o += align_up(nf * g.win * sizeof(float), 256);
   off_audio = o;
   o += align_up(3 * (size_t)B * Lpad * sizeof(float), 256);
+  if (plan->fam_ok) o += align_up(nf * plan->fam.fsf * sizeof(float), 256);
   total = o;
 }
 
@@ -768,6 +828,41 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   if (h_launch_ms) {
     RFX_HIP(events.create(n_iter + 2));
     RFX_HIP(hipEventRecord(events.ev[0], stream));
+  }
+  if (plan->fam_ok) {
+    const FamGeom& f = plan->fam;
+    float* S_slots = (float*)(ws + oa + align_up(3 * (size_t)B * Lpad * sizeof(float), 256));
+    RFX_HIP(launch_fam_repack(d_mag, S_slots, plan->d_fam_binof, (long long)B * T, g.fs, f.fsf, stream));
+    FamGlArgs fa{};
+    fa.g = f;
+    fa.S = S_slots;
+    fa.angles0 = (const cf*)d_angles0;
+    fa.fs_plain = g.fs;
+    fa.audio_stride = (size_t)Lpad;
+    fa.frames = frames;
+    fa.tw1 = plan->d_fam_tw;
+    fa.twa = plan->d_fam_tw + (size_t)kFamRows * f.h;
+    fa.win = plan->d_win;
+    fa.mom = momentum / (1.f + momentum);
+    fa.seed = seed;
+    fa.B = B;
+    fa.T = T;
+    fa.L = L;
+    const long long nframes = (long long)B * T, slots = (long long)plan->num_cus * plan->fam_wgs_per_cu;
+    const int nblocks = (int)(nframes < slots ? nframes : slots);
+    for (int it = 0; it <= n_iter; ++it) {
+      fa.x_cur = gen[(it + 2) % 3];
+      fa.x_prev = gen[(it + 1) % 3];
+      RFX_HIP(launch_fam_gl(it == 0 ? 0 : it == 1 ? 1 : 2, fa, nblocks, stream));
+      const bool last = it == n_iter;
+      RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+      if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
+    }
+    if (h_launch_ms) {
+      RFX_HIP(hipEventSynchronize(events.ev[n_iter + 1]));
+      for (int i = 0; i <= n_iter; ++i) RFX_HIP(hipEventElapsedTime(&h_launch_ms[i], events.ev[i], events.ev[i + 1]));
+    }
+    return RFX_OK;
   }
   GenGlArgs a{};
   a.g = g;

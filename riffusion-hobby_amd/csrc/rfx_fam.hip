@@ -1,0 +1,277 @@
+// rfx_fam.hip - Griffin-Lim (torchaudio.transforms.GriffinLim as constructed at riffusion/spectrogram_converter.py:62-73,
+// called at :204) for the ROW FAMILY of STFT geometries: n_fft = 40 h, win_length = 10 h, any hop - the reference's default
+// 400 / 100 / 10 ms (spectrogram_params.py:24-27, :62-81) at 48, 32, 24, 16 and 8 kHz (cli.py:43 takes the sample rate from
+// the input file).  Round 2 / 3 ran these on the generic engine (rfx_generic.hip: a complex FFT of n_fft / 2 points over a
+// runtime digit list, eleven barrier-separated phases per frame, 587 tiles/s at 48 kHz against 1960 at 44.1 kHz); here they
+// get the specialised engine's factorisation (rfx_core.h) with h in place of 441:
+//     P1   thread n' < h          pruned 40-point transform of the ten windowed samples h j + n' (only the window's quarter of
+//                                 the frame is ever touched), twiddle g(n')^k1 -> 21 rows x h in LDS
+//     A    thread (row, i < RB)   radix-RA butterfly down the row, twiddle W_h^{i p}
+//     B    thread (row, p < RA)   radix-RB butterfly -> RB slots in registers: Z = S a / (|a| + 1e-16), inverse butterfly
+//     A'   inverse of A           P1'  pruned inverse -> ten windowed synthesis samples -> HBM
+// Five barriers per frame.  `a` is the spectrum of x_k - m x_{k-1}: the momentum term of the reference's
+// `rebuilt - m tprev` is applied in the time domain (the STFT is linear, rfx_gl.hip), so no spectrum ever reaches HBM.
+// One frame per workgroup trip (grid-stride), gen_fold_kernel (rfx_generic.hip) overlap-adds the frames: two launches per
+// iteration, same buffers and same random stream as the generic engine, which remains the fallback for every other geometry.
+// |S| arrives in the plan's plain bin-ordered layout and is re-ordered ONCE per call into slot order (thread t's slot s at
+// s * nthr + t: every wave-wide load is whole lines); duplicate slots get the same magnitude.
+#include <hip/hip_runtime.h>
+
+#include "rfx_fam_core.h"
+#include "rfx_frame.hip.h"  // buffer-descriptor loads / stores (SRD in SGPRs + one 32-bit lane offset: no 64-bit per-lane addresses)
+#include "rfx_kernels.h"
+
+namespace rfx {
+
+constexpr int fam_threads(int ra, int rb) {
+  int n = ra * rb;
+  if (kFamRows * rb > n) n = kFamRows * rb;
+  if (kFamRows * ra > n) n = kFamRows * ra;
+  return (n + 63) / 64 * 64;
+}
+
+#ifndef RFX_FAM_STREAM_AUX
+#define RFX_FAM_STREAM_AUX kAuxNT  // |S| is read once per iteration: streamed past L2
+#endif
+
+size_t fam_lds_bytes(const FamGeom& g) { return sizeof(cf) * (size_t)kFamRows * g.rs; }
+
+// the thread's RA - 1 pass-A twiddles, fetched in two batches (L1-resident table: rb (ra - 1) entries)
+template <int RA>
+struct FamTwA {
+  cf w[RA];
+  rsrc_t src;
+  unsigned voff;
+  template <int HALF>
+  __device__ __forceinline__ void load() {
+#pragma unroll
+    for (int p = HALF ? RA / 2 + 1 : 1; p < (HALF ? RA : RA / 2 + 1); ++p) {
+      const v2f t = ld2(src, voff, (unsigned)(p - 1) * 8u);
+      w[p] = cf{t.x, t.y};
+    }
+  }
+};
+
+// MODE 0: Z = S * angles0 (injected or drawn) -> synthesis; MODE 1: analysis of x_0; MODE 2: analysis of x_k - m x_{k-1}
+// 128 VGPRs: two 512-thread workgroups per CU at 48 kHz.  Every table / HBM value is requested one barrier before its use:
+//   before P1 | A : first half of the pass-A twiddles            before A | B : the frame's |S|
+//   before B' | A': first half of the conjugate twiddles          before A'| P1': g(n')^k1 and the Hann samples (P1' and the NEXT
+//   frame's P1 use the same values), and the next frame's ten input samples
+// Phases are fenced for the compiler's scheduler (left alone it hoists the next phase's loads over the current butterfly and
+// spills 70 registers).
+template <int MODE, int RA, int RB>
+__global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_waves_per_eu(4))) fam_gl_kernel(FamGlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* cube = reinterpret_cast<cf*>(smem);
+  constexpr int H = RA * RB;
+  constexpr int NT = fam_threads(RA, RB);
+  const int tid = threadIdx.x;
+  const int rs = a.g.rs;
+  const bool act1 = tid < H;
+  const int npr = act1 ? tid : H - 1;  // idle lanes shadow the last active one (loads only, never stores)
+  const bool actA = tid < kFamRows * RB;
+  const int tA = actA ? tid : kFamRows * RB - 1;
+  const int rowA = tA / RB, iA = tA - rowA * RB;
+  const bool actB = tid < kFamRows * RA;
+  const int tB = actB ? tid : kFamRows * RA - 1;
+  const int rowB = tB / RA, pB = tB - rowB * RA;
+  cf* const rowa = cube + rowA * rs + iA;
+  cf* const rowb = cube + rowB * rs + pB * RB;
+  const rsrc_t tw1 = make_rsrc(a.tw1, (size_t)kFamRows * H * sizeof(cf));
+  const rsrc_t win = make_rsrc(a.win, (size_t)10 * H * sizeof(float));
+  const unsigned npr4 = (unsigned)npr * 4u, npr8 = (unsigned)npr * 8u, tB4 = (unsigned)tB * 4u;
+  const float oscale = 2.0f / (float)a.g.n_fft;
+  const long long nframes = (long long)a.B * a.T;
+
+  FamTwA<RA> wa;
+  wa.src = make_rsrc(a.twa, (size_t)RB * (RA - 1) * sizeof(cf));
+  wa.voff = (unsigned)iA * ((RA - 1) * 8u);
+  // g(n')^k1 for k1 = 1..10 and 20 only (fam_g_pow)
+  cf w1[12];
+  float wv[10], u[10], pv[10];
+  auto load_tables = [&] {
+#pragma unroll
+    for (int k = 1; k <= 11; ++k) {
+      const v2f t = ld2(tw1, npr8, (unsigned)(k <= 10 ? k : 20) * (H * 8u));
+      w1[k] = cf{t.x, t.y};
+    }
+#pragma unroll
+    for (int j = 0; j < 10; ++j) wv[j] = ld1(win, npr4, (unsigned)j * (H * 4u));
+  };
+  auto g1 = [&w1](int k) { return fam_g_pow(w1, k); };
+  // frame fr is centred on sample hop * fr of the reflect-padded estimate (torch.stft center=True): the window covers
+  // positions hop * fr - 5 h .. hop * fr + 5 h - 1
+  auto load_samples = [&](long long gf) {
+    const int clip = (int)(gf / a.T), fr = (int)(gf - (long long)clip * a.T);
+    const rsrc_t xc = make_rsrc(a.x_cur + (size_t)clip * a.audio_stride, (size_t)a.L * sizeof(float));
+    const rsrc_t xp = make_rsrc(a.x_prev + (size_t)clip * a.audio_stride, (size_t)a.L * sizeof(float));
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const unsigned p4 = (unsigned)reflect_index(a.g.hop * fr + (j - 5) * H + npr, a.L) * 4u;
+      u[j] = ld1(xc, p4, 0);
+      if (MODE == 2) pv[j] = ld1(xp, p4, 0);
+    }
+  };
+  // u = (x_k - m x_{k-1}) * window, formed as soon as the samples are in (ten registers across P1' instead of twenty)
+  auto window_samples = [&] {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) u[j] = (MODE == 2 ? fmaf(-a.mom, pv[j], u[j]) : u[j]) * wv[j];
+  };
+  if (MODE != 0 && (long long)blockIdx.x < nframes) {
+    load_tables();
+    load_samples(blockIdx.x);
+    window_samples();
+  }
+
+#ifdef RFX_FAM_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+  int nfr = 0;
+#define FSTAMP(i) do { unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define FSTAMP(i) ((void)0)
+#endif
+  for (long long gf = blockIdx.x; gf < nframes; gf += gridDim.x) {
+    const rsrc_t S = make_rsrc(a.S + (size_t)gf * a.g.fsf, (size_t)a.g.fsf * sizeof(float));
+    cf R[RB];
+    FSTAMP(0);
+    if (MODE != 0) {
+      if (act1) fam_p1_forward_store(u, g1, cube, npr, rs);
+      RFX_SCHED_FENCE();
+      wa.template load<0>();
+      FSTAMP(1);
+      __syncthreads();
+      FSTAMP(2);
+      RFX_SCHED_FENCE();
+      if (actA)
+        fam_pass_a_forward<RA, RB>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int half) {
+          if (half == 1) wa.template load<1>();
+          RFX_SCHED_FENCE();
+        });
+      RFX_SCHED_FENCE();
+      float Sv[RB];
+#pragma unroll
+      for (int s = 0; s < RB; ++s) Sv[s] = ld1<RFX_FAM_STREAM_AUX>(S, tB4, (unsigned)s * (NT * 4u));
+      FSTAMP(3);
+      __syncthreads();
+      FSTAMP(2);
+      RFX_SCHED_FENCE();
+      fam_pass_b_forward<RA, RB>(rowb, 0, R);
+#pragma unroll
+      for (int s = 0; s < RB; ++s) R[s] = gl_project(R[s], Sv[s]);
+    } else {
+      const long long clipfr = gf;
+#pragma unroll
+      for (int s = 0; s < RB; ++s) {
+        bool cj;
+        const int bin = fam_slot_bin(a.g, rowB, pB, s, &cj);
+        cf ang;
+        if (a.angles0) ang = a.angles0[(size_t)clipfr * a.fs_plain + bin];
+        else ang = rand_unit_pair(a.seed, (unsigned long long)clipfr * a.g.n_stft + bin);  // the generic engine's stream
+        const float sv = ld1<RFX_FAM_STREAM_AUX>(S, tB4, (unsigned)s * (NT * 4u));
+        R[s] = cf{sv * ang.re, cj ? -(sv * ang.im) : sv * ang.im};
+      }
+    }
+    if (actB) fam_pass_b_inverse<RA, RB>(rowb, 0, R);
+    RFX_SCHED_FENCE();
+    wa.template load<0>();
+    FSTAMP(4);
+    __syncthreads();
+    FSTAMP(2);
+    RFX_SCHED_FENCE();
+    if (actA)
+      fam_pass_a_inverse<RA, RB>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int half) {
+        if (half == 1) wa.template load<1>();
+        RFX_SCHED_FENCE();
+      });
+    RFX_SCHED_FENCE();
+    load_tables();
+    FSTAMP(5);
+    __syncthreads();
+    FSTAMP(2);
+    RFX_SCHED_FENCE();
+    // the next frame's samples are requested here and arrive underneath P1' (requested before the barrier, together with the
+    // tables, the 61 loads of this phase queue up behind each other: 4 us of issue time per frame, measured)
+    const bool more = MODE != 0 && gf + gridDim.x < nframes;
+    if (more) load_samples(gf + gridDim.x);
+    RFX_SCHED_FENCE();
+    {
+      float y[10];
+      fam_p1_load_inverse(cube, g1, y, npr, rs);
+      if (act1) {
+        const rsrc_t out = make_rsrc(a.frames + (size_t)gf * a.g.win, (size_t)10 * H * sizeof(float));
+#pragma unroll
+        for (int j = 0; j < 10; ++j) st1(y[j] * (wv[j] * oscale), out, npr4, (unsigned)j * (H * 4u));
+      }
+    }
+    RFX_SCHED_FENCE();
+    if (more) window_samples();
+    RFX_SCHED_FENCE();
+    FSTAMP(6);
+    __syncthreads();  // the next frame's first LDS stores overwrite rows other threads are still gathering in P1'
+    FSTAMP(2);
+#ifdef RFX_FAM_TIMING
+    ++nfr;
+#endif
+  }
+#ifdef RFX_FAM_TIMING
+  if (MODE == 2 && (blockIdx.x == 7 || blockIdx.x == 300) && (threadIdx.x == 0 || threadIdx.x == 256 || threadIdx.x == 448))
+    printf("fam_gl timing, block %d of %d, thread %d (100 MHz ticks per frame, %d frames): P1 %.1f | barriers %.1f | A %.1f | B+proj+B' %.1f | A' %.1f | P1' %.1f | loop top %.1f\n",
+           (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, nfr, (double)tacc[1] / nfr, (double)tacc[2] / nfr, (double)tacc[3] / nfr, (double)tacc[4] / nfr, (double)tacc[5] / nfr,
+           (double)tacc[6] / nfr, (double)tacc[0] / nfr);
+#endif
+}
+
+// |S| (or any per-bin float array) from plain bin order [nframes][fs_plain] to slot order [nframes][fsf]
+__global__ void __launch_bounds__(256) fam_repack_kernel(const float* __restrict__ plain, float* __restrict__ slots,
+                                                         const int* __restrict__ bin_of, int fs_plain, int fsf) {
+  const size_t fr = blockIdx.x;
+  const int i = blockIdx.y * blockDim.x + threadIdx.x;
+  if (i >= fsf) return;
+  const int b = bin_of[i];
+  slots[fr * fsf + i] = b >= 0 ? plain[fr * fs_plain + b] : 0.f;
+}
+
+using FamGlFn = void (*)(FamGlArgs);
+template <int RA, int RB>
+static FamGlFn fam_fn(int mode) {
+  return mode == 0 ? fam_gl_kernel<0, RA, RB> : mode == 1 ? fam_gl_kernel<1, RA, RB> : fam_gl_kernel<2, RA, RB>;
+}
+static FamGlFn fam_fn(const FamGeom& g, int mode) {
+  switch (g.h) {
+    case 80: return fam_fn<10, 8>(mode);
+    case 160: return fam_fn<16, 10>(mode);
+    case 240: return fam_fn<16, 15>(mode);
+    case 320: return fam_fn<20, 16>(mode);
+    case 441: return fam_fn<21, 21>(mode);
+    case 480: return fam_fn<24, 20>(mode);
+    default: return nullptr;
+  }
+}
+
+hipError_t prepare_fam_kernels(const FamGeom& g) {
+  for (int mode = 0; mode < 3; ++mode) {
+    const FamGlFn fn = fam_fn(g, mode);
+    if (!fn) return hipErrorInvalidValue;
+    const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam_lds_bytes(g));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+int fam_blocks_per_cu(const FamGeom& g) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)fam_fn(g, 2), g.nthr, fam_lds_bytes(g)) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+
+hipError_t launch_fam_gl(int mode, const FamGlArgs& a, int nblocks, hipStream_t stream) {
+  hipLaunchKernelGGL(fam_fn(a.g, mode), dim3(nblocks), dim3(a.g.nthr), fam_lds_bytes(a.g), stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_fam_repack(const float* plain, float* slots, const int* bin_of, long long nframes, int fs_plain, int fsf, hipStream_t stream) {
+  hipLaunchKernelGGL(fam_repack_kernel, dim3((unsigned)nframes, (fsf + 255) / 256), dim3(256), 0, stream, plain, slots, bin_of, fs_plain, fsf);
+  return hipGetLastError();
+}
+
+}  // namespace rfx

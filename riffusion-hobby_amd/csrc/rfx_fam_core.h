@@ -1,0 +1,143 @@
+// rfx_fam_core.h - per-thread arithmetic of the ROW-FAMILY frame transform: every geometry with n_fft = 40 h and
+// win_length = 10 h, i.e. the reference's default 400 ms / 100 ms (riffusion/spectrogram_params.py:24-27, :62-81) at any
+// sample rate that is a multiple of 100 Hz - 48 kHz (h = 480), 32 kHz, 24 kHz, 16 kHz, 8 kHz; 44.1 kHz (h = 441) is the
+// specialised engine's own case (rfx_core.h) and runs here only as a cross-check.  Written once for the gfx950 kernels of
+// rfx_fam.hip (hipcc) and for the host emulator of the CPU tests (g++), like rfx_core.h / rfx_gen_core.h.
+//
+// Same decomposition as rfx_core.h with h in place of 441:
+//   sample index  n = h J + n'      J = 15..24 (only the 10 windowed blocks are non-zero), n' = 0..h-1
+//   bin index     k = k1 + 40 k'    k1 = 0..39, k' = 0..h-1
+//   X[k1 + 40 k'] = sum_{n'} w_h^{n' k'} g(n')^{k1} sum_{j=0..9} u[h j + n'] w40^{j k1},   g(n') = exp(-2 pi i (n' + 15 h) / (40 h))
+// P1 is rfx_core.h's pruned 40-point transform of ten reals (rows k1 = 0..20 kept, the rest are conjugates); the 21 rows are
+// h-point complex FFTs done in place in two passes, h = RA * RB:
+//   pass A (thread = (row, i), i < RB):  y = DFT_RA(row[i + q RB]),  row[i + p RB] = y[p] W_h^{i p}
+//   pass B (thread = (row, p), p < RA):  R = DFT_RB(row[p RB + q])   ->  R[s] = X[k1 + 40 (p + RA s)]   (stays in registers)
+// (decimation in frequency; the inverse retraces it, decimation in time).  The 21 h row outputs ("slots") cover the
+// 20 h + 1 one-sided bins: slot k <= n_fft / 2 holds X[k], slot k > n_fft / 2 holds conj(X[n_fft - k]); bins on rows 0 and
+// 20 appear twice.  Everything Griffin-Lim does between the two transforms is per bin and commutes with conjugation, so
+// slots are independent bins (rfx_core.h).  The hop length is free: frames are overlap-added by gen_fold_kernel.
+#pragma once
+#include "rfx_gen_core.h"
+
+namespace rfx {
+
+constexpr int kFamRows = 21;
+
+struct FamGeom {
+  int h;         // n_fft / 40 = win_length / 10
+  int ra, rb;    // h = ra * rb
+  int nthr;      // threads per workgroup: max(h, 21 rb, 21 ra) rounded up to whole waves
+  int rs;        // LDS elements between rows of the cube (>= h)
+  int fsf;       // floats per frame of the slot-ordered magnitudes: rb * nthr (thread t's slot s at s * nthr + t)
+  int n_fft, win, hop, n_stft;
+};
+
+// the digit pairs the kernels are instantiated for (both digits implemented by gen_dft)
+RFX_HD bool fam_digits(int h, int* ra, int* rb) {
+  switch (h) {
+    case 80: *ra = 10; *rb = 8; return true;     // 8 kHz
+    case 160: *ra = 16; *rb = 10; return true;   // 16 kHz
+    case 240: *ra = 16; *rb = 15; return true;   // 24 kHz
+    case 320: *ra = 20; *rb = 16; return true;   // 32 kHz
+    case 441: *ra = 21; *rb = 21; return true;   // 44.1 kHz (cross-check of the specialised engine)
+    case 480: *ra = 24; *rb = 20; return true;   // 48 kHz
+    default: return false;
+  }
+}
+RFX_HD bool fam_make_geom(int n_fft, int win, int hop, FamGeom* g) {
+  if (n_fft % 40 != 0 || win * 4 != n_fft || win % 10 != 0 || hop < 1) return false;
+  const int h = n_fft / 40;
+  int ra, rb;
+  if (!fam_digits(h, &ra, &rb)) return false;
+  g->h = h;
+  g->ra = ra;
+  g->rb = rb;
+  int n = h;
+  if (kFamRows * rb > n) n = kFamRows * rb;
+  if (kFamRows * ra > n) n = kFamRows * ra;
+  g->nthr = (n + 63) / 64 * 64;
+  g->rs = h;
+  g->fsf = rb * g->nthr;
+  g->n_fft = n_fft;
+  g->win = win;
+  g->hop = hop;
+  g->n_stft = n_fft / 2 + 1;
+  return true;
+}
+// bin held by slot s of pass-B thread (row k1, p); *conj_out set when the slot holds the conjugate of that bin
+RFX_HD int fam_slot_bin(const FamGeom& g, int k1, int p, int s, bool* conj_out) {
+  const int k = k1 + 40 * (p + g.ra * s);
+  const bool c = k > g.n_fft / 2;
+  if (conj_out) *conj_out = c;
+  return c ? g.n_fft - k : k;
+}
+
+// g(n')^k1 from the eleven values a thread keeps, w[1..10] = g^1 .. g^10 and w[11] = g^20: g^(20-k) = g^20 conj(g^k) - one more
+// complex product for the rows 11..19 instead of nine more table loads per frame and eighteen registers
+RFX_HD cf fam_g_pow(const cf (&w)[12], int k) { return k <= 10 ? w[k] : k == 20 ? w[11] : cmulc(w[11], w[20 - k]); }
+
+// ---- P1: thread n' < h.  tw1(k1) = g(n')^k1
+template <class TW>
+RFX_HD void fam_p1_forward_store(const float (&u)[10], TW tw1, cf* cube, int npr, int rs) {
+  p1_forward_rows(u, [&](int k1, cf v) { cube[k1 * rs + npr] = k1 == 0 ? v : cmul(v, tw1(k1)); });
+}
+// un-normalised: the caller multiplies by 2 / n_fft (and the synthesis window)
+template <class TW>
+RFX_HD void fam_p1_load_inverse(const cf* cube, TW tw1, float (&y)[10], int npr, int rs) {
+  p1_inverse_rows([&](int k1) { return cube[k1 * rs + npr]; }, [&](int k1, cf c) { return k1 == 0 ? c : cmulc(c, tw1(k1)); }, y);
+}
+
+// ---- pass A: thread (row, i).  tw(p) = W_h^{i p}, p = 1..RA-1.  `stage(0)` runs once the row values are requested and
+// `stage(1)` once the outputs 0..RA/2 have been stored: the kernels fetch the twiddles 1..RA/2 / RA/2+1..RA-1 there (two
+// batches of registers instead of 2 (RA - 1) next to the butterfly's own 4 RA).
+template <int RA, int RB, class TW, class STAGE = NoStage>
+RFX_HD void fam_pass_a_forward(cf* row, int i, TW tw, STAGE stage = STAGE()) {
+  cf v[RA], y[RA];
+  const cf none[RA] = {};
+#pragma unroll
+  for (int q = 0; q < RA; ++q) v[q] = row[i + q * RB];
+  stage(0);
+  gen_dft<RA, false>(v, y, none);
+  row[i] = y[0];
+#pragma unroll
+  for (int p = 1; p <= RA / 2; ++p) row[i + p * RB] = cmul(y[p], tw(p));
+  stage(1);
+#pragma unroll
+  for (int p = RA / 2 + 1; p < RA; ++p) row[i + p * RB] = cmul(y[p], tw(p));
+}
+// inverse: the twiddles come first.  `stage(0)` before the first half is read, `stage(1)` before the second
+template <int RA, int RB, class TW, class STAGE = NoStage>
+RFX_HD void fam_pass_a_inverse(cf* row, int i, TW tw, STAGE stage = STAGE()) {
+  cf v[RA], y[RA];
+  const cf none[RA] = {};
+  stage(0);
+  v[0] = row[i];
+#pragma unroll
+  for (int p = 1; p <= RA / 2; ++p) v[p] = cmulc(row[i + p * RB], tw(p));
+  stage(1);
+#pragma unroll
+  for (int p = RA / 2 + 1; p < RA; ++p) v[p] = cmulc(row[i + p * RB], tw(p));
+  gen_dft<RA, true>(v, y, none);
+#pragma unroll
+  for (int q = 0; q < RA; ++q) row[i + q * RB] = y[q];
+}
+
+// ---- pass B: thread (row, p).  R[s] = slot k1 + 40 (p + RA s)
+template <int RA, int RB>
+RFX_HD void fam_pass_b_forward(const cf* row, int p, cf (&R)[RB]) {
+  cf v[RB];
+  const cf none[RB] = {};
+#pragma unroll
+  for (int q = 0; q < RB; ++q) v[q] = row[p * RB + q];
+  gen_dft<RB, false>(v, R, none);
+}
+template <int RA, int RB>
+RFX_HD void fam_pass_b_inverse(cf* row, int p, const cf (&Z)[RB]) {
+  cf y[RB];
+  const cf none[RB] = {};
+  gen_dft<RB, true>(Z, y, none);
+#pragma unroll
+  for (int q = 0; q < RB; ++q) row[p * RB + q] = y[q];
+}
+
+}  // namespace rfx

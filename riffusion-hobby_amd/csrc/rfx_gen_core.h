@@ -174,6 +174,14 @@ template <> struct GenRootTab<16> {
   static constexpr float c[16] = {1.00000000000000000000f, 0.92387953251128673848f, 0.70710678118654757274f, 0.38268343236508983729f, 0.00000000000000006123f, -0.38268343236508972627f, -0.70710678118654746172f, -0.92387953251128673848f, -1.00000000000000000000f, -0.92387953251128684951f, -0.70710678118654768376f, -0.38268343236509033689f, -0.00000000000000018370f, 0.38268343236509000382f, 0.70710678118654735069f, 0.92387953251128651644f};
   static constexpr float s[16] = {0.00000000000000000000f, 0.38268343236508978178f, 0.70710678118654746172f, 0.92387953251128673848f, 1.00000000000000000000f, 0.92387953251128673848f, 0.70710678118654757274f, 0.38268343236508989280f, 0.00000000000000012246f, -0.38268343236508967076f, -0.70710678118654746172f, -0.92387953251128651644f, -1.00000000000000000000f, -0.92387953251128662746f, -0.70710678118654768376f, -0.38268343236509039240f};
 };
+template <> struct GenRootTab<20> {
+  static constexpr float c[20] = {1.00000000000000000000f, 0.95105651629515353118f, 0.80901699437494745126f, 0.58778525229247313710f, 0.30901699437494745126f, 0.00000000000000006123f, -0.30901699437494734024f, -0.58778525229247302608f, -0.80901699437494734024f, -0.95105651629515353118f, -1.00000000000000000000f, -0.95105651629515375323f, -0.80901699437494756229f, -0.58778525229247324813f, -0.30901699437494756229f, -0.00000000000000018370f, 0.30901699437494722922f, 0.58778525229247291506f, 0.80901699437494734024f, 0.95105651629515353118f};
+  static constexpr float s[20] = {0.00000000000000000000f, 0.30901699437494739575f, 0.58778525229247313710f, 0.80901699437494745126f, 0.95105651629515353118f, 1.00000000000000000000f, 0.95105651629515364220f, 0.80901699437494745126f, 0.58778525229247324813f, 0.30901699437494750677f, 0.00000000000000012246f, -0.30901699437494689615f, -0.58778525229247302608f, -0.80901699437494734024f, -0.95105651629515353118f, -1.00000000000000000000f, -0.95105651629515364220f, -0.80901699437494756229f, -0.58778525229247335915f, -0.30901699437494761780f};
+};
+template <> struct GenRootTab<24> {
+  static constexpr float c[24] = {1.00000000000000000000f, 0.96592582628906831221f, 0.86602540378443870761f, 0.70710678118654757274f, 0.50000000000000011102f, 0.25881904510252073948f, 0.00000000000000006123f, -0.25881904510252062845f, -0.49999999999999977796f, -0.70710678118654746172f, -0.86602540378443870761f, -0.96592582628906820119f, -1.00000000000000000000f, -0.96592582628906831221f, -0.86602540378443881863f, -0.70710678118654790580f, -0.50000000000000044409f, -0.25881904510252062845f, -0.00000000000000018370f, 0.25881904510252029539f, 0.50000000000000011102f, 0.70710678118654735069f, 0.86602540378443837454f, 0.96592582628906809017f};
+  static constexpr float s[24] = {0.00000000000000000000f, 0.25881904510252073948f, 0.49999999999999994449f, 0.70710678118654746172f, 0.86602540378443859659f, 0.96592582628906831221f, 1.00000000000000000000f, 0.96592582628906831221f, 0.86602540378443870761f, 0.70710678118654757274f, 0.49999999999999994449f, 0.25881904510252101703f, 0.00000000000000012246f, -0.25881904510252079499f, -0.49999999999999972244f, -0.70710678118654712865f, -0.86602540378443837454f, -0.96592582628906831221f, -1.00000000000000000000f, -0.96592582628906842324f, -0.86602540378443859659f, -0.70710678118654768376f, -0.50000000000000044409f, -0.25881904510252157214f};
+};
 template <int R, bool INV>
 RFX_HD cf gen_const_twiddle(cf x, int e) {  // x * exp(-/+ 2 pi i e / R); e is a compile-time constant wherever this is called
   e %= R;
@@ -270,6 +278,17 @@ RFX_HD void gen_dft(const cf (&v)[R], cf (&y)[R], const cf (&root)[R]) {
     gen_dft_ct<5, 3, INV>(v, y);
   } else if constexpr (R == 16) {
     gen_dft_ct<4, 4, INV>(v, y);
+  } else if constexpr (R == 20) {  // 20, 21, 24: digits of the row transforms of rfx_fam_core.h
+    gen_dft_ct<4, 5, INV>(v, y);
+  } else if constexpr (R == 24) {
+    gen_dft_ct<8, 3, INV>(v, y);
+  } else if constexpr (R == 21) {
+    cf x[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) x[i] = v[i];
+    dft21<INV>(x);
+#pragma unroll
+    for (int i = 0; i < 21; ++i) y[i] = x[i];
   } else {
 #pragma unroll
     for (int p = 0; p < R; ++p) {

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "rfx_core.h"
 #include "rfx_gen_core.h"
+#include "rfx_fam_core.h"
 
 namespace rfx {
 
@@ -199,6 +200,29 @@ hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B
 hipError_t launch_gen_mel(const float* mag, float* mel_tm, const float* band_wt, const int* band_lo, const int* band_len, long long nframes,
                           int fs, int M, int Mpad, hipStream_t stream);
 hipError_t launch_mel_transpose(const float* mel_tm, float* mel, int B, int T, int M, int Mpad, hipStream_t stream);
+
+// ---- row-family Griffin-Lim (rfx_fam.hip): n_fft = 40 h, win_length = 10 h; frames are folded by launch_gen_fold
+struct FamGlArgs {
+  FamGeom g;
+  const float* S;        // [B*T][g.fsf] magnitudes in slot order (launch_fam_repack)
+  const cf* angles0;     // mode 0: optional injected initial angles in the plan's PLAIN layout [B*T][fs_plain] (drawn from `seed` when null)
+  int fs_plain;
+  const float* x_cur;    // modes 1, 2: x_k      [B][audio_stride], L valid samples per clip
+  const float* x_prev;   // mode 2:     x_{k-1}
+  size_t audio_stride;
+  float* frames;         // [B*T][win] windowed, scaled synthesis frames
+  const cf* tw1;         // [21][h]      g(n')^k1
+  const cf* twa;         // [rb][ra-1]   W_h^{i p}
+  const float* win;      // [win]
+  float mom;             // momentum / (1 + momentum)
+  unsigned long long seed;
+  int B, T, L;
+};
+hipError_t prepare_fam_kernels(const FamGeom& g);
+size_t fam_lds_bytes(const FamGeom& g);
+int fam_blocks_per_cu(const FamGeom& g);
+hipError_t launch_fam_gl(int mode, const FamGlArgs& a, int nblocks, hipStream_t stream);  // mode 0 init, 1 first iteration, 2 iteration
+hipError_t launch_fam_repack(const float* plain, float* slots, const int* bin_of, long long nframes, int fs_plain, int fsf, hipStream_t stream);
 
 // image / PCM codecs
 hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out, int N, int H, int W, int C, hipStream_t s);

@@ -47,10 +47,13 @@ class RfxParams(ctypes.Structure):
 class RfxPlanOptions(ctypes.Structure):
     """rfx_plan_options of include/rfx.h."""
 
-    _fields_ = [("struct_size", ctypes.c_uint32), ("gl_form", ctypes.c_int32), ("gl_frames_per_slot", ctypes.c_int32)]
+    _fields_ = [("struct_size", ctypes.c_uint32), ("gl_form", ctypes.c_int32), ("gl_frames_per_slot", ctypes.c_int32),
+                ("frame_engine", ctypes.c_int32)]
 
 
 GL_FORMS = {"auto": 0, "runs": 1, "frames": 2}  # rfx_gl_form
+FRAME_ENGINES = {"auto": 0, "generic": 1}       # rfx_frame_engine
+GL_ENGINE_NAMES = {0: "specialised", 1: "generic", 2: "row-family"}  # rfx_plan_griffinlim_engine
 
 
 class RfxError(RuntimeError):
@@ -65,6 +68,7 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_num_bins": (c_int, []),
     "rfx_plan_frame_stride": (c_int, [c_void_p]),
     "rfx_plan_is_generic": (c_int, [c_void_p]),
+    "rfx_plan_griffinlim_engine": (c_int, [c_void_p]),
     "rfx_mel_scale_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_plan_create": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "rfx_plan_create_ex": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
@@ -202,10 +206,12 @@ def mel_filterbank(
 class Plan:
     """Owns one rfx_plan (device constants for one parameter set on one device)."""
 
-    def __init__(self, params: T.Any, device: torch.device, gl_form: str = "auto"):
+    def __init__(self, params: T.Any, device: torch.device, gl_form: str = "auto", frame_engine: str = "auto"):
         self.lib = load_library()
         if gl_form not in GL_FORMS:
             raise ValueError(f"gl_form must be one of {sorted(GL_FORMS)}, got {gl_form!r}")
+        if frame_engine not in FRAME_ENGINES:
+            raise ValueError(f"frame_engine must be one of {sorted(FRAME_ENGINES)}, got {frame_engine!r}")
         self.gl_form = gl_form
         self.device = device
         self.n_fft, self.win_length, self.hop_length = params.n_fft, params.win_length, params.hop_length
@@ -224,7 +230,7 @@ class Plan:
         cp = RfxParams(params.sample_rate, self.n_fft, self.win_length, self.hop_length, self.n_mels, params.max_mel_iters)
         handle = c_void_p()
         self.device = device = resolve_device(device)
-        opt = RfxPlanOptions(ctypes.sizeof(RfxPlanOptions), GL_FORMS[gl_form], 0)
+        opt = RfxPlanOptions(ctypes.sizeof(RfxPlanOptions), GL_FORMS[gl_form], 0, FRAME_ENGINES[frame_engine])
         check(
             self.lib.rfx_plan_create_ex(
                 ctypes.byref(cp), self.window.data_ptr(), self.melfb.data_ptr(), device.index, ctypes.byref(opt), ctypes.byref(handle)
@@ -233,6 +239,7 @@ class Plan:
         self.handle = handle
         self.frame_stride = self.lib.rfx_plan_frame_stride(self.handle)
         self.generic = bool(self.lib.rfx_plan_is_generic(self.handle))
+        self.griffinlim_engine = GL_ENGINE_NAMES[self.lib.rfx_plan_griffinlim_engine(self.handle)]
 
     def __del__(self):
         try:
@@ -482,17 +489,19 @@ _plans: T.Dict[T.Tuple[T.Any, int, str], Plan] = {}
 _plans_lock = threading.Lock()
 
 
-def get_plan(params: T.Any, device: T.Union[str, torch.device], gl_form: str = "auto") -> Plan:
+def get_plan(params: T.Any, device: T.Union[str, torch.device], gl_form: str = "auto", frame_engine: str = "auto") -> Plan:
     """Plans are immutable and cached per (frozen params, device, options): constructing a converter per
     request, as the reference's server does (server.py:159), costs a dictionary lookup.
 
     `gl_form` picks the Griffin-Lim device form (rfx_plan_options.gl_form): "auto" (per call, from the batch
-    shape), "runs" (always the run-based fused kernel) or "frames" (always the per-frame kernel + fold)."""
+    shape), "runs" (always the run-based fused kernel) or "frames" (always the per-frame kernel + fold);
+    `frame_engine` = "generic" keeps Griffin-Lim of the 40 h / 10 h geometries (48 kHz ...) on the generic FFT engine
+    instead of the row-family kernels (rfx_plan_options.frame_engine; cross-checks)."""
     dev = resolve_device(device)  # 'cuda' is keyed by the GPU it means now, not bound for good to the first one used
-    key = (params, dev.index, gl_form)
+    key = (params, dev.index, gl_form, frame_engine)
     with _plans_lock:
         plan = _plans.get(key)
         if plan is None:
-            plan = Plan(params, dev, gl_form)
+            plan = Plan(params, dev, gl_form, frame_engine)
             _plans[key] = plan
     return plan

@@ -1,0 +1,137 @@
+// Host-side emulator of the ROW-FAMILY frame transform (csrc/rfx_fam_core.h).  TEST INFRASTRUCTURE ONLY, built with g++ by
+// tests/test_fam_core.py: it runs the per-thread functions the gfx950 kernels of rfx_fam.hip inline, looping over the logical
+// threads of a workgroup phase by phase (a loop boundary stands where the kernel has a barrier).
+#include <cmath>
+#include <vector>
+#include "../../riffusion-hobby_amd/csrc/rfx_fam_core.h"
+
+using namespace rfx;
+
+namespace {
+struct FamTables {
+  std::vector<cf> tw1, twa;
+};
+void make_tables(const FamGeom& g, FamTables& t) {
+  const double PI2 = 6.283185307179586476925286766559;
+  t.tw1.resize((size_t)kFamRows * g.h);
+  for (int k1 = 0; k1 < kFamRows; ++k1)
+    for (int n = 0; n < g.h; ++n) {
+      const long long e = ((long long)k1 * (n + 15 * g.h)) % g.n_fft;
+      t.tw1[(size_t)k1 * g.h + n] = cf{(float)cos(PI2 * (double)e / g.n_fft), (float)(-sin(PI2 * (double)e / g.n_fft))};
+    }
+  t.twa.resize((size_t)g.rb * (g.ra - 1));
+  for (int i = 0; i < g.rb; ++i)
+    for (int p = 1; p < g.ra; ++p) {
+      const int e = (i * p) % g.h;
+      t.twa[(size_t)i * (g.ra - 1) + p - 1] = cf{(float)cos(PI2 * e / (double)g.h), (float)(-sin(PI2 * e / (double)g.h))};
+    }
+}
+template <int RA, int RB>
+void forward(const FamGeom& g, const FamTables& t, const float* win_samples, std::vector<cf>& slots) {
+  std::vector<cf> cube((size_t)kFamRows * g.rs);
+  for (int n = 0; n < g.h; ++n) {  // P1
+    float u[10];
+    for (int j = 0; j < 10; ++j) u[j] = win_samples[j * g.h + n];
+    cf w[12];  // what a thread of the kernel holds: g^1 .. g^10 and g^20
+    for (int k = 1; k <= 11; ++k) w[k] = t.tw1[(size_t)(k <= 10 ? k : 20) * g.h + n];
+    fam_p1_forward_store(u, [&](int k1) { return fam_g_pow(w, k1); }, cube.data(), n, g.rs);
+  }
+  for (int tid = 0; tid < kFamRows * RB; ++tid) {  // pass A
+    const int row = tid / RB, i = tid % RB;
+    fam_pass_a_forward<RA, RB>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)i * (RA - 1) + p - 1]; });
+  }
+  slots.assign((size_t)g.fsf, cf{0.f, 0.f});
+  for (int tid = 0; tid < kFamRows * RA; ++tid) {  // pass B
+    const int row = tid / RA, p = tid % RA;
+    cf R[RB];
+    fam_pass_b_forward<RA, RB>(cube.data() + (size_t)row * g.rs, p, R);
+    for (int s = 0; s < RB; ++s) slots[(size_t)s * g.nthr + tid] = R[s];
+  }
+}
+template <int RA, int RB>
+void inverse(const FamGeom& g, const FamTables& t, const std::vector<cf>& slots, float* win_samples) {
+  std::vector<cf> cube((size_t)kFamRows * g.rs);
+  for (int tid = 0; tid < kFamRows * RA; ++tid) {
+    const int row = tid / RA, p = tid % RA;
+    cf Z[RB];
+    for (int s = 0; s < RB; ++s) Z[s] = slots[(size_t)s * g.nthr + tid];
+    fam_pass_b_inverse<RA, RB>(cube.data() + (size_t)row * g.rs, p, Z);
+  }
+  for (int tid = 0; tid < kFamRows * RB; ++tid) {
+    const int row = tid / RB, i = tid % RB;
+    fam_pass_a_inverse<RA, RB>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)i * (RA - 1) + p - 1]; });
+  }
+  const float sc = 2.0f / (float)g.n_fft;
+  for (int n = 0; n < g.h; ++n) {
+    float y[10];
+    cf w[12];
+    for (int k = 1; k <= 11; ++k) w[k] = t.tw1[(size_t)(k <= 10 ? k : 20) * g.h + n];
+    fam_p1_load_inverse(cube.data(), [&](int k1) { return fam_g_pow(w, k1); }, y, n, g.rs);
+    for (int j = 0; j < 10; ++j) win_samples[j * g.h + n] = y[j] * sc;
+  }
+}
+template <int RA, int RB>
+int run(const FamGeom& g, int dir, const float* in, float* out) {
+  FamTables t;
+  make_tables(g, t);
+  std::vector<cf> slots;
+  if (dir == 0) {  // in: the win windowed samples of a frame; out: one-sided spectrum (n_fft/2 + 1 complex), duplicates checked
+    forward<RA, RB>(g, t, in, slots);
+    std::vector<int> seen(g.n_stft, 0);
+    for (int k1 = 0; k1 < kFamRows; ++k1)
+      for (int p = 0; p < RA; ++p)
+        for (int s = 0; s < RB; ++s) {
+          bool cj;
+          const int bin = fam_slot_bin(g, k1, p, s, &cj);
+          const cf v = slots[(size_t)s * g.nthr + k1 * RA + p];
+          const cf x{v.re, cj ? -v.im : v.im};
+          if (seen[bin]) {  // a duplicate slot must agree with the first one
+            const float dr = out[2 * bin] - x.re, di = out[2 * bin + 1] - x.im;
+            const float mag = fabsf(x.re) + fabsf(x.im) + 1e-20f;
+            if (fabsf(dr) + fabsf(di) > 1e-3f * mag + 1e-3f) return -2;
+          }
+          seen[bin]++;
+          out[2 * bin] = x.re;
+          out[2 * bin + 1] = x.im;
+        }
+    for (int b = 0; b < g.n_stft; ++b)
+      if (seen[b] < 1 || seen[b] > 2) return -3;
+    return 0;
+  }
+  // in: one-sided spectrum; out: the win samples the window covers of its inverse real FFT
+  slots.assign((size_t)g.fsf, cf{0.f, 0.f});
+  for (int k1 = 0; k1 < kFamRows; ++k1)
+    for (int p = 0; p < RA; ++p)
+      for (int s = 0; s < RB; ++s) {
+        bool cj;
+        const int bin = fam_slot_bin(g, k1, p, s, &cj);
+        slots[(size_t)s * g.nthr + k1 * RA + p] = cf{in[2 * bin], cj ? -in[2 * bin + 1] : in[2 * bin + 1]};
+      }
+  inverse<RA, RB>(g, t, slots, out);
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+// dir 0: forward, dir 1: inverse; rs_pad: extra LDS elements between cube rows (the kernels pad by up to 7)
+int emu_fam_transform(int n_fft, int dir, int rs_pad, const float* in, float* out) {
+  FamGeom g;
+  if (!fam_make_geom(n_fft, n_fft / 4, n_fft / 40, &g)) return -1;
+  g.rs += rs_pad;
+  switch (g.h) {
+    case 80: return run<10, 8>(g, dir, in, out);
+    case 160: return run<16, 10>(g, dir, in, out);
+    case 240: return run<16, 15>(g, dir, in, out);
+    case 320: return run<20, 16>(g, dir, in, out);
+    case 441: return run<21, 21>(g, dir, in, out);
+    case 480: return run<24, 20>(g, dir, in, out);
+  }
+  return -1;
+}
+int emu_fam_geom(int n_fft, int win, int hop, int* out6) {
+  FamGeom g;
+  if (!fam_make_geom(n_fft, win, hop, &g)) return -1;
+  out6[0] = g.h; out6[1] = g.ra; out6[2] = g.rb; out6[3] = g.nthr; out6[4] = g.fsf; out6[5] = g.n_stft;
+  return 0;
+}
+}

@@ -10,7 +10,7 @@ from riffusion.util import image_util
 B, T = int(os.environ.get("B", 64)), 512
 for rate in [int(r) for r in os.environ.get("RATES", "48000,22050,44100").split(",")]:
     p = SpectrogramParams(sample_rate=rate, max_frequency=min(10000, rate // 2))
-    plan = _hip.get_plan(p, "cuda")
+    plan = _hip.get_plan(p, "cuda", gl_form=os.environ.get("GLFORM", "auto"), frame_engine=os.environ.get("ENGINE", "auto"))
     tiles = torch.from_numpy(np.random.default_rng(0).integers(0, 256, size=(B, 512, T, 3), dtype=np.uint8)).cuda()
     lut = torch.from_numpy(image_util.decode_lut(0.25, 30e6)).cuda()
     def decode(seed):
@@ -28,6 +28,6 @@ for rate in [int(r) for r in os.environ.get("RATES", "48000,22050,44100").split(
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record(); l2 = plan.inverse_mel(plan.image_decode(tiles, False, lut), 1, seed=9); e[1].record()
         plan.griffinlim(l2, B, T, 32, 0.99, seed=3); e[2].record(); torch.cuda.synchronize()
-    print(f"{rate} Hz ({'generic' if plan.generic else 'specialised'} engine, n_fft {p.n_fft}): decode {B} tiles {1e3*(t1-t0):.1f} ms = {B/(t1-t0):.0f} tiles/s "
+    print(f"{rate} Hz ({'generic' if plan.generic else 'specialised'} plan, Griffin-Lim on the {plan.griffinlim_engine} engine, n_fft {p.n_fft}): decode {B} tiles {1e3*(t1-t0):.1f} ms = {B/(t1-t0):.0f} tiles/s "
           f"(InverseMelScale {e[0].elapsed_time(e[1]):.1f} ms, Griffin-Lim 32 {e[1].elapsed_time(e[2]):.1f} ms); "
           f"forward {1e3*(t2-t1):.2f} ms = {B/(t2-t1):.0f} images/s; finite={bool(torch.isfinite(mel).all())}")
