@@ -262,14 +262,15 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
                 fam_make_geom(params->n_fft, params->win_length, params->hop_length, &fam);
   if (fam_ok) {
     // pad the rows by up to seven elements (bank spread of the row-to-row accesses) as long as that costs no resident workgroup
-    const size_t plain = fam_lds_bytes(fam);
+    const size_t plain = fam_lds_bytes(fam) + fam_static_lds_bytes(fam);
     int per_cu = (int)((160u * 1024u) / plain);
     if (per_cu > 1024 / fam.nthr) per_cu = 1024 / fam.nthr;
     if (per_cu < 1) fam_ok = false;
     for (int pad = 7; fam_ok && pad > 0; --pad) {
       FamGeom t = fam;
       t.rs = fam.h + pad;
-      if (fam_lds_bytes(t) * per_cu <= 160u * 1024u) { fam = t; break; }
+      if (fam_row_stride_even(fam) && t.rs % 2) continue;
+      if ((fam_lds_bytes(t) + fam_static_lds_bytes(t)) * per_cu <= 160u * 1024u) { fam = t; break; }
     }
   }
   RFX_ON_DEVICE(device);

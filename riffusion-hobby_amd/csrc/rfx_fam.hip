@@ -9,7 +9,7 @@
 //     A    thread (row, i < RB)   radix-RA butterfly down the row, twiddle W_h^{i p}
 //     B    thread (row, p < RA)   radix-RB butterfly -> RB slots in registers: Z = S a / (|a| + 1e-16), inverse butterfly
 //     A'   inverse of A           P1'  pruned inverse -> ten windowed synthesis samples -> HBM
-// Five barriers per frame.  `a` is the spectrum of x_k - m x_{k-1}: the momentum term of the reference's
+// Four barriers per frame.  `a` is the spectrum of x_k - m x_{k-1}: the momentum term of the reference's
 // `rebuilt - m tprev` is applied in the time domain (the STFT is linear, rfx_gl.hip), so no spectrum ever reaches HBM.
 // One frame per workgroup trip (grid-stride), gen_fold_kernel (rfx_generic.hip) overlap-adds the frames: two launches per
 // iteration, same buffers and same random stream as the generic engine, which remains the fallback for every other geometry.
@@ -30,24 +30,48 @@ constexpr int fam_threads(int ra, int rb) {
   return (n + 63) / 64 * 64;
 }
 
+// Measured at 48 kHz / 16 kHz, 64 tiles x 32 iterations (tools/probe_fam.py): 16-byte LDS accesses in pass B together with a
+// raised issue priority for the B phase 52.6 -> 50.4 ms / 19.2 -> 18.2 ms (each alone: 51.0 / 52.6 ms); both halves of the
+// forward pass-A twiddles requested before the butterfly: 57.6 ms (registers) - off.
+#ifndef RFX_FAM_VEC
+#define RFX_FAM_VEC 1
+#endif
+#ifndef RFX_FAM_PRIO
+#define RFX_FAM_PRIO 1
+#endif
+#ifndef RFX_FAM_TW_EARLY
+#define RFX_FAM_TW_EARLY 0
+#endif
 #ifndef RFX_FAM_STREAM_AUX
 #define RFX_FAM_STREAM_AUX kAuxNT  // |S| is read once per iteration: streamed past L2
 #endif
 
+bool fam_row_stride_even(const FamGeom& g) { return RFX_FAM_VEC && g.rb % 2 == 0; }
 size_t fam_lds_bytes(const FamGeom& g) { return sizeof(cf) * (size_t)kFamRows * g.rs; }
 
-// the thread's RA - 1 pass-A twiddles, fetched in two batches (L1-resident table: rb (ra - 1) entries)
-template <int RA>
+// Where the pass-A twiddles W_h^{i p} live: in LDS (a static array next to the cube: the compiler then knows that cube stores
+// never alias twiddle reads) wherever two workgroups still share a CU with it - every geometry but 48 kHz, whose cube leaves
+// 1.2 KB - and in the L1-resident global table otherwise.
+constexpr bool fam_twiddles_in_lds(int ra, int rb) { return ra * rb != 480; }
+size_t fam_static_lds_bytes(const FamGeom& g) { return fam_twiddles_in_lds(g.ra, g.rb) ? sizeof(cf) * (size_t)g.rb * (g.ra - 1) : 0; }
+
+// the thread's RA - 1 pass-A twiddles, fetched in two batches
+template <int RA, bool LDS>
 struct FamTwA {
   cf w[RA];
   rsrc_t src;
   unsigned voff;
+  const cf* tab;  // LDS row of this thread
   template <int HALF>
   __device__ __forceinline__ void load() {
 #pragma unroll
     for (int p = HALF ? RA / 2 + 1 : 1; p < (HALF ? RA : RA / 2 + 1); ++p) {
-      const v2f t = ld2(src, voff, (unsigned)(p - 1) * 8u);
-      w[p] = cf{t.x, t.y};
+      if (LDS) {
+        w[p] = tab[p - 1];
+      } else {
+        const v2f t = ld2(src, voff, (unsigned)(p - 1) * 8u);
+        w[p] = cf{t.x, t.y};
+      }
     }
   }
 };
@@ -83,9 +107,15 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
   const float oscale = 2.0f / (float)a.g.n_fft;
   const long long nframes = (long long)a.B * a.T;
 
-  FamTwA<RA> wa;
+  constexpr bool VEC = RFX_FAM_VEC && RB % 2 == 0;  // the host picks an even row stride then (fam_row_stride_even)
+  constexpr bool TWL = fam_twiddles_in_lds(RA, RB);
+  __shared__ __attribute__((aligned(16))) cf twa_lds[TWL ? RB * (RA - 1) : 1];
+  if (TWL)
+    for (int i = tid; i < RB * (RA - 1); i += NT) twa_lds[i] = a.twa[i];  // (the first barrier of the loop precedes its first use)
+  FamTwA<RA, TWL> wa;
   wa.src = make_rsrc(a.twa, (size_t)RB * (RA - 1) * sizeof(cf));
   wa.voff = (unsigned)iA * ((RA - 1) * 8u);
+  wa.tab = twa_lds + iA * (RA - 1);
   // g(n')^k1 for k1 = 1..10 and 20 only (fam_g_pow)
   cf w1[12];
   float wv[10], u[10], pv[10];
@@ -138,13 +168,16 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
       if (act1) fam_p1_forward_store(u, g1, cube, npr, rs);
       RFX_SCHED_FENCE();
       wa.template load<0>();
+#if RFX_FAM_TW_EARLY
+      wa.template load<1>();
+#endif
       FSTAMP(1);
       __syncthreads();
       FSTAMP(2);
       RFX_SCHED_FENCE();
       if (actA)
         fam_pass_a_forward<RA, RB>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int half) {
-          if (half == 1) wa.template load<1>();
+          if (half == 1 && !RFX_FAM_TW_EARLY) wa.template load<1>();
           RFX_SCHED_FENCE();
         });
       RFX_SCHED_FENCE();
@@ -155,7 +188,10 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
       __syncthreads();
       FSTAMP(2);
       RFX_SCHED_FENCE();
-      fam_pass_b_forward<RA, RB>(rowb, 0, R);
+#if RFX_FAM_PRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
+      fam_pass_b_forward<RA, RB, VEC>(rowb, 0, R);
 #pragma unroll
       for (int s = 0; s < RB; ++s) R[s] = gl_project(R[s], Sv[s]);
     } else {
@@ -171,7 +207,10 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
         R[s] = cf{sv * ang.re, cj ? -(sv * ang.im) : sv * ang.im};
       }
     }
-    if (actB) fam_pass_b_inverse<RA, RB>(rowb, 0, R);
+    if (actB) fam_pass_b_inverse<RA, RB, VEC>(rowb, 0, R);
+#if RFX_FAM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     RFX_SCHED_FENCE();
     wa.template load<0>();
     FSTAMP(4);
@@ -207,8 +246,9 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
     if (more) window_samples();
     RFX_SCHED_FENCE();
     FSTAMP(6);
-    __syncthreads();  // the next frame's first LDS stores overwrite rows other threads are still gathering in P1'
-    FSTAMP(2);
+    // no barrier here when a P1 follows: its stores go to column n' of the rows - exactly the elements this thread has just
+    // read in P1' - and nobody else touches a column between these two phases (a wave's LDS operations execute in order)
+    if (MODE == 0) __syncthreads();  // (mode 0 goes straight to the next frame's B', which writes whole rows)
 #ifdef RFX_FAM_TIMING
     ++nfr;
 #endif
@@ -260,7 +300,7 @@ hipError_t prepare_fam_kernels(const FamGeom& g) {
 
 int fam_blocks_per_cu(const FamGeom& g) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)fam_fn(g, 2), g.nthr, fam_lds_bytes(g)) != hipSuccess || n < 1) n = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)fam_fn(g, 2), g.nthr, fam_lds_bytes(g)) != hipSuccess || n < 1) n = 1;  // (counts the static LDS too)
   return n;
 }
 

@@ -122,22 +122,59 @@ RFX_HD void fam_pass_a_inverse(cf* row, int i, TW tw, STAGE stage = STAGE()) {
   for (int q = 0; q < RA; ++q) row[i + q * RB] = y[q];
 }
 
-// ---- pass B: thread (row, p).  R[s] = slot k1 + 40 (p + RA s)
-template <int RA, int RB>
+// ---- pass B: thread (row, p).  R[s] = slot k1 + 40 (p + RA s).  `row` points at the thread's RB contiguous elements; with
+// VEC (RB even and the block 16-byte aligned: even row stride) the kernels move two elements per LDS instruction.
+RFX_HD void fam_ld_pair(const cf* p, cf& a, cf& b, bool vec) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (vec) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 t = *reinterpret_cast<const v4*>(p);
+    a = cf{t.x, t.y};
+    b = cf{t.z, t.w};
+    return;
+  }
+#endif
+  (void)vec;
+  a = p[0];
+  b = p[1];
+}
+RFX_HD void fam_st_pair(cf* p, cf a, cf b, bool vec) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (vec) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<v4*>(p) = v4{a.re, a.im, b.re, b.im};
+    return;
+  }
+#endif
+  (void)vec;
+  p[0] = a;
+  p[1] = b;
+}
+template <int RA, int RB, bool VEC = false>
 RFX_HD void fam_pass_b_forward(const cf* row, int p, cf (&R)[RB]) {
   cf v[RB];
   const cf none[RB] = {};
+  if (VEC && RB % 2 == 0) {
 #pragma unroll
-  for (int q = 0; q < RB; ++q) v[q] = row[p * RB + q];
+    for (int q = 0; q + 1 < RB; q += 2) fam_ld_pair(row + p * RB + q, v[q], v[q + 1], true);
+  } else {
+#pragma unroll
+    for (int q = 0; q < RB; ++q) v[q] = row[p * RB + q];
+  }
   gen_dft<RB, false>(v, R, none);
 }
-template <int RA, int RB>
+template <int RA, int RB, bool VEC = false>
 RFX_HD void fam_pass_b_inverse(cf* row, int p, const cf (&Z)[RB]) {
   cf y[RB];
   const cf none[RB] = {};
   gen_dft<RB, true>(Z, y, none);
+  if (VEC && RB % 2 == 0) {
 #pragma unroll
-  for (int q = 0; q < RB; ++q) row[p * RB + q] = y[q];
+    for (int q = 0; q + 1 < RB; q += 2) fam_st_pair(row + p * RB + q, y[q], y[q + 1], true);
+  } else {
+#pragma unroll
+    for (int q = 0; q < RB; ++q) row[p * RB + q] = y[q];
+  }
 }
 
 }  // namespace rfx

@@ -219,8 +219,10 @@ struct FamGlArgs {
   int B, T, L;
 };
 hipError_t prepare_fam_kernels(const FamGeom& g);
-size_t fam_lds_bytes(const FamGeom& g);
+size_t fam_lds_bytes(const FamGeom& g);         // dynamic: the cube
+size_t fam_static_lds_bytes(const FamGeom& g);  // static: the pass-A twiddles where they fit
 int fam_blocks_per_cu(const FamGeom& g);
+bool fam_row_stride_even(const FamGeom& g);     // the kernels use 16-byte LDS accesses in pass B: rows must start 16-byte aligned
 hipError_t launch_fam_gl(int mode, const FamGlArgs& a, int nblocks, hipStream_t stream);  // mode 0 init, 1 first iteration, 2 iteration
 hipError_t launch_fam_repack(const float* plain, float* slots, const int* bin_of, long long nframes, int fs_plain, int fsf, hipStream_t stream);
 
