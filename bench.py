@@ -26,6 +26,8 @@ Extra objects on the JSON line:
                  divided by the launch duration measured with HIP events on the launch stream.
   cpu_baseline - the CPU oracle (oracle/riffusion_oracle.py, a torch-CPU port of the reference's
                  torchaudio path) timed on this host on ONE tile of the same workload.
+  other_sample_rates - the same decode step at 48 kHz (n_fft 19200 / win 4800 / hop 480: Griffin-Lim on the
+                 row-family kernels of csrc/rfx_fam.hip), measured after the timed region; context only.
 """
 import argparse
 import ctypes
@@ -58,6 +60,7 @@ def parse():
                          "decode-stereo64 = configs[3] (512 stereo tiles, Griffin-Lim 64, sharded over the ranks)")
     ap.add_argument("--global-clips", type=int, default=512, help="decode-stereo64: clips in the sharded batch")
     ap.add_argument("--no-forward", action="store_true", help="skip the embedded configs[2] forward measurement")
+    ap.add_argument("--no-other-rates", action="store_true", help="skip the embedded 48 kHz decode measurement (row-family Griffin-Lim engine)")
     ap.add_argument("--gather", choices=["none", "rank0", "all"], default="none",
                     help="decode-stereo64: which clips a rank returns (own shard / everything on rank 0 / everything everywhere)")
     return ap.parse_args()
@@ -636,12 +639,47 @@ def main():
             latency[name + "_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
         latency["note"] = "SpectrogramImageConverter.audio_from_spectrogram_images on ONE 512x512 tile, D2H copy of the PCM included (small-batch Griffin-Lim kernels)"
 
+    # ---- the same decode step at 48 kHz (cli.py:43 takes the sample rate from the input file; spectrogram_params.py:62-81 derives
+    # n_fft 19200 / win 4800 / hop 480 from it): Griffin-Lim on the row-family kernels (csrc/rfx_fam.hip).  Context, not the headline.
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_rates:
+        other = {}
+        for rate in (48000,):
+            p2 = SpectrogramParams(sample_rate=rate, num_griffin_lim_iters=args.iters)
+            plan2 = _hip.get_plan(p2, dev)
+
+            def step2(seed):
+                mel2 = plan2.image_decode(tiles, False, lut)
+                lin2 = plan2.inverse_mel(mel2, 1, seed=seed)
+                w2 = plan2.griffinlim(lin2, B, T, args.iters, 0.99, seed=seed + 1)
+                return plan2.pcm16(w2, channels=1, normalize=True)[0], lin2
+
+            step2(0)
+            torch.cuda.synchronize(dev)
+            n2 = max(2, min(args.steps, 5))
+            t2 = time.perf_counter()
+            for k in range(n2):
+                pcm2, lin2 = step2(50 + k)
+            torch.cuda.synchronize(dev)
+            dt2 = (time.perf_counter() - t2) / n2
+            e2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e2[0].record()
+            plan2.griffinlim(lin2, B, T, args.iters, 0.99, seed=3)
+            e2[1].record()
+            torch.cuda.synchronize(dev)
+            other[str(rate)] = {"tiles_per_s": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3), "steps": n2,
+                                "griffinlim_ms": round(e2[0].elapsed_time(e2[1]), 3), "griffinlim_engine": plan2.griffinlim_engine,
+                                "n_fft": p2.n_fft, "hop_length": p2.hop_length, "finite": bool(torch.isfinite(pcm2.float()).all()),
+                                "workload": f"batch={B} synthetic 512x512 mono uint8 tiles -> audio at {rate} Hz, Griffin-Lim {args.iters}"}
+
     # ---- configs[2] (audio -> mel image) measured in the same run and carried on the same line
     fwd = None
     if not args.no_forward:
         fwd = forward_measure(args, world, rank, dev, distributed, with_cpu=False)
     if rank == 0:
         out["single_tile_latency"] = latency
+        if other is not None:
+            out["other_sample_rates"] = other
         if fwd is not None:
             out["forward"] = {k: fwd[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "stages")}
         if world == 1 and not args.no_cpu_baseline:

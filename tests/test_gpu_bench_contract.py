@@ -40,6 +40,8 @@ def test_headline_line_small_batch():
     assert f["unit"] == "images/s" and f["value"] > 0 and f["roofline"]["kernel"] == "rfx::stft_mel2_kernel" and 0 < f["roofline"]["true_flops_frac"] < 1
     assert {"image_decode_ms", "inverse_mel_ms", "griffinlim_ms", "pcm16_ms"} <= set(d["stages"])
     assert 0 < d["single_tile_latency"]["mono_ms"] < d["single_tile_latency"]["stereo_ms"] * 1.5
+    o = d["other_sample_rates"]["48000"]
+    assert o["griffinlim_engine"] == "row-family" and o["n_fft"] == 19200 and o["tiles_per_s"] > 0 and o["finite"] is True
 
 
 def test_distributed_launch_one_rank_keeps_stdout_clean():
