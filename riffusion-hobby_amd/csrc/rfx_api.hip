@@ -728,6 +728,27 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
   if (Lw <= plan->p.n_fft / 2)
     return fail(RFX_ERR_INVALID, "rfx_stft: reflect padding needs more than n_fft/2 = " + std::to_string(plan->p.n_fft / 2) + " samples");
   RFX_ON_DEVICE(plan->device);
+  if (plan->fam_ok) {  // row-family kernels (rfx_fam.hip), same plain layout as the generic engine's
+    const FamGeom& f = plan->fam;
+    FamFwdArgs fa{};
+    fa.g = f;
+    fa.wave = d_wave;
+    fa.wave_stride = (size_t)Lw;
+    fa.Lw = Lw;
+    fa.mag = d_mag_slots;
+    fa.spec = (cf*)d_spec_slots;
+    fa.fs_plain = plan->gg.fs;
+    fa.tw1 = plan->d_fam_tw;
+    fa.twa = plan->d_fam_tw + (size_t)kFamRows * f.h;
+    fa.win = plan->d_win;
+    fa.B = B;
+    fa.T = stft_frames(plan, Lw);
+    const long long nframes = (long long)B * fa.T, slots = (long long)plan->num_cus * plan->fam_wgs_per_cu;
+    const int nblocks = (int)(nframes < slots ? nframes : slots);
+    if (d_mag_slots) RFX_HIP(launch_fam_fwd(0, fa, nblocks, (hipStream_t)stream));
+    if (d_spec_slots) RFX_HIP(launch_fam_fwd(1, fa, nblocks, (hipStream_t)stream));
+    return RFX_OK;
+  }
   if (plan->generic) {
     GenStftArgs g{};
     g.g = plan->gg;
@@ -1083,7 +1104,7 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
     if (rc) return rc;
     RFX_HIP(launch_gen_mel(mag, mel_tm, plan->d_band_wt, plan->d_band_lo, plan->d_band_lo + plan->Mpad, (long long)B * T, plan->gg.fs,
-                           plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+                           plan->p.n_mels, plan->Mpad, plan->imel.f_lo, plan->imel.f_hi, (hipStream_t)stream));
     RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
     return RFX_OK;
   }
@@ -1157,7 +1178,7 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
     float* mel_tm = (float*)((char*)d_workspace + align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256));
     RFX_HIP(launch_gen_pack(d_lin_bft, mag, false, B, plan->n_stft, T, plan->gg.fs, (hipStream_t)stream));
     RFX_HIP(launch_gen_mel(mag, mel_tm, plan->d_band_wt, plan->d_band_lo, plan->d_band_lo + plan->Mpad, (long long)B * T, plan->gg.fs,
-                           plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+                           plan->p.n_mels, plan->Mpad, plan->imel.f_lo, plan->imel.f_hi, (hipStream_t)stream));
     RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
     return RFX_OK;
   }

@@ -261,6 +261,109 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
 #endif
 }
 
+// ---- forward: Spectrogram(power=None) [+ abs] of the family geometries (spectrogram_converter.py:47-59, :179-182).  Same P1 /
+// A / B as above; the frame then changes places through LDS - once every row has been read the cube's memory becomes the
+// bin-ordered frame, each bin written by its primary slot (the direct one where a bin has two) - and leaves in whole lines, in
+// the plan's plain layout [B*T][fs] (what rfx_stft hands out and gen_mel_kernel reads).  MODE 0: |X|, MODE 1: X.
+template <int MODE, int RA, int RB>
+__global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_waves_per_eu(4))) fam_fwd_kernel(FamFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* cube = reinterpret_cast<cf*>(smem);
+  float* magl = reinterpret_cast<float*>(smem);
+  constexpr int H = RA * RB;
+  constexpr int NT = fam_threads(RA, RB);
+  constexpr bool VEC = RFX_FAM_VEC && RB % 2 == 0;
+  constexpr bool TWL = fam_twiddles_in_lds(RA, RB);
+  const int tid = threadIdx.x;
+  const int rs = a.g.rs;
+  const bool act1 = tid < H;
+  const int npr = act1 ? tid : H - 1;
+  const bool actA = tid < kFamRows * RB;
+  const int tA = actA ? tid : kFamRows * RB - 1;
+  const int rowA = tA / RB, iA = tA - rowA * RB;
+  const bool actB = tid < kFamRows * RA;
+  const int tB = actB ? tid : kFamRows * RA - 1;
+  const int rowB = tB / RA, pB = tB - rowB * RA;
+  cf* const rowa = cube + rowA * rs + iA;
+  cf* const rowb = cube + rowB * rs + pB * RB;
+  const rsrc_t tw1 = make_rsrc(a.tw1, (size_t)kFamRows * H * sizeof(cf));
+  const rsrc_t win = make_rsrc(a.win, (size_t)10 * H * sizeof(float));
+  const unsigned npr4 = (unsigned)npr * 4u, npr8 = (unsigned)npr * 8u;
+  const long long nframes = (long long)a.B * a.T;
+  const int fs = a.fs_plain, n_stft = a.g.n_stft;
+
+  __shared__ __attribute__((aligned(16))) cf twa_lds[TWL ? RB * (RA - 1) : 1];
+  if (TWL)
+    for (int i = tid; i < RB * (RA - 1); i += NT) twa_lds[i] = a.twa[i];
+  FamTwA<RA, TWL> wa;
+  wa.src = make_rsrc(a.twa, (size_t)RB * (RA - 1) * sizeof(cf));
+  wa.voff = (unsigned)iA * ((RA - 1) * 8u);
+  wa.tab = twa_lds + iA * (RA - 1);
+  cf w1[12];
+  float wv[10], u[10];
+  auto g1 = [&w1](int k) { return fam_g_pow(w1, k); };
+  auto load_frame_inputs = [&](long long gf) {  // tables and the frame's ten samples (reflect-padded like torch.stft center=True)
+#pragma unroll
+    for (int k = 1; k <= 11; ++k) {
+      const v2f t = ld2(tw1, npr8, (unsigned)(k <= 10 ? k : 20) * (H * 8u));
+      w1[k] = cf{t.x, t.y};
+    }
+    const int clip = (int)(gf / a.T), fr = (int)(gf - (long long)clip * a.T);
+    const rsrc_t x = make_rsrc(a.wave + (size_t)clip * a.wave_stride, (size_t)a.Lw * sizeof(float));
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      wv[j] = ld1(win, npr4, (unsigned)j * (H * 4u));
+      u[j] = ld1(x, (unsigned)reflect_index(a.g.hop * fr + (j - 5) * H + npr, a.Lw) * 4u, 0);
+    }
+  };
+  if ((long long)blockIdx.x < nframes) load_frame_inputs(blockIdx.x);
+  for (long long gf = blockIdx.x; gf < nframes; gf += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) u[j] *= wv[j];
+    if (act1) fam_p1_forward_store(u, g1, cube, npr, rs);
+    RFX_SCHED_FENCE();
+    wa.template load<0>();
+    __syncthreads();
+    RFX_SCHED_FENCE();
+    if (actA)
+      fam_pass_a_forward<RA, RB>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int half) {
+        if (half == 1) wa.template load<1>();
+        RFX_SCHED_FENCE();
+      });
+    RFX_SCHED_FENCE();
+    __syncthreads();
+    RFX_SCHED_FENCE();
+    cf R[RB];
+    fam_pass_b_forward<RA, RB, VEC>(rowb, 0, R);
+    RFX_SCHED_FENCE();
+    __syncthreads();  // every row has been read: the memory is now the bin-ordered frame
+    if (actB) {
+#pragma unroll
+      for (int s = 0; s < RB; ++s) {
+        bool cj;
+        const int bin = fam_slot_bin(a.g, rowB, pB, s, &cj);
+        if (!cj || (rowB != 0 && rowB != 20)) {  // rows 0 and 20 hold their bins twice: the direct slot writes
+          if (MODE == 1) cube[bin] = cf{R[s].re, cj ? -R[s].im : R[s].im};
+          // v_sqrt_f32 (1 ulp) instead of the IEEE expansion: |X| carries ~1e-7 relative error from the transform anyway
+          else magl[bin] = __builtin_amdgcn_sqrtf(fmaf(R[s].re, R[s].re, R[s].im * R[s].im));
+        }
+      }
+    }
+    RFX_SCHED_FENCE();
+    __syncthreads();
+    if (gf + gridDim.x < nframes) load_frame_inputs(gf + gridDim.x);  // in flight underneath the output loop
+    if (MODE == 1) {
+      cf* __restrict__ out = a.spec + (size_t)gf * fs;
+      for (int k = tid; k < fs; k += NT) out[k] = k < n_stft ? cube[k] : cf{0.f, 0.f};
+    } else {
+      float* __restrict__ out = a.mag + (size_t)gf * fs;
+      for (int k = tid; k < fs; k += NT) out[k] = k < n_stft ? magl[k] : 0.f;  // (the padding of the frame stride stays zero)
+    }
+    RFX_SCHED_FENCE();
+    __syncthreads();  // the next frame's P1 overwrites the frame
+  }
+}
+
 // |S| (or any per-bin float array) from plain bin order [nframes][fs_plain] to slot order [nframes][fsf]
 __global__ void __launch_bounds__(256) fam_repack_kernel(const float* __restrict__ plain, float* __restrict__ slots,
                                                          const int* __restrict__ bin_of, int fs_plain, int fsf) {
@@ -288,7 +391,33 @@ static FamGlFn fam_fn(const FamGeom& g, int mode) {
   }
 }
 
+using FamFwdFn = void (*)(FamFwdArgs);
+template <int RA, int RB>
+static FamFwdFn fam_fwd_fn(int mode) {
+  return mode == 0 ? fam_fwd_kernel<0, RA, RB> : fam_fwd_kernel<1, RA, RB>;
+}
+static FamFwdFn fam_fwd_fn(const FamGeom& g, int mode) {
+  switch (g.h) {
+    case 80: return fam_fwd_fn<10, 8>(mode);
+    case 160: return fam_fwd_fn<16, 10>(mode);
+    case 240: return fam_fwd_fn<16, 15>(mode);
+    case 320: return fam_fwd_fn<20, 16>(mode);
+    case 441: return fam_fwd_fn<21, 21>(mode);
+    case 480: return fam_fwd_fn<24, 20>(mode);
+    default: return nullptr;
+  }
+}
+
+hipError_t launch_fam_fwd(int mode, const FamFwdArgs& a, int nblocks, hipStream_t stream) {
+  hipLaunchKernelGGL(fam_fwd_fn(a.g, mode), dim3(nblocks), dim3(a.g.nthr), fam_lds_bytes(a.g), stream, a);
+  return hipGetLastError();
+}
+
 hipError_t prepare_fam_kernels(const FamGeom& g) {
+  for (int mode = 0; mode < 2; ++mode) {
+    const hipError_t e = hipFuncSetAttribute((const void*)fam_fwd_fn(g, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam_lds_bytes(g));
+    if (e != hipSuccess) return e;
+  }
   for (int mode = 0; mode < 3; ++mode) {
     const FamGlFn fn = fam_fn(g, mode);
     if (!fn) return hipErrorInvalidValue;

@@ -198,7 +198,7 @@ hipError_t launch_gen_fold(const float* frames, const float* win, float* out, co
 hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_mel(const float* mag, float* mel_tm, const float* band_wt, const int* band_lo, const int* band_len, long long nframes,
-                          int fs, int M, int Mpad, hipStream_t stream);
+                          int fs, int M, int Mpad, int f_lo, int f_hi, hipStream_t stream);  // [f_lo, f_hi): bins with a non-zero filterbank row
 hipError_t launch_mel_transpose(const float* mel_tm, float* mel, int B, int T, int M, int Mpad, hipStream_t stream);
 
 // ---- row-family Griffin-Lim (rfx_fam.hip): n_fft = 40 h, win_length = 10 h; frames are folded by launch_gen_fold
@@ -218,6 +218,21 @@ struct FamGlArgs {
   unsigned long long seed;
   int B, T, L;
 };
+// forward STFT of the family geometries into the plan's plain layout (mode 0: |X| floats, mode 1: X complex)
+struct FamFwdArgs {
+  FamGeom g;
+  const float* wave;     // [B][wave_stride], Lw valid samples each
+  size_t wave_stride;
+  int Lw;
+  float* mag;            // mode 0: [B*T][fs_plain]
+  cf* spec;              // mode 1: [B*T][fs_plain]
+  int fs_plain;
+  const cf* tw1;
+  const cf* twa;
+  const float* win;
+  int B, T;
+};
+hipError_t launch_fam_fwd(int mode, const FamFwdArgs& a, int nblocks, hipStream_t stream);
 hipError_t prepare_fam_kernels(const FamGeom& g);
 size_t fam_lds_bytes(const FamGeom& g);         // dynamic: the cube
 size_t fam_static_lds_bytes(const FamGeom& g);  // static: the pass-A twiddles where they fit

@@ -199,6 +199,20 @@ def test_row_family_griffinlim_matches_oracle_and_generic_engine(O, rate):
         s, s2 = snr_db(want, got), snr_db(other, got)
         print(f"{rate} Hz row-family griffinlim n_iter={n}: {s:.1f} dB vs oracle (floor {floor:.0f}), {s2:.1f} dB vs the generic engine")
         assert got.shape == want.shape and s >= floor and s2 >= agree
+    # forward transform (rfx_stft, and through it the mel path): row-family kernel against the oracle and the generic engine
+    wave = synthetic_wave(2, p.hop_length * 61 + 7, seed=rate + 3)
+    ref = O.stft_complex(wave, op)
+    mf, sf, Tn = fam.stft(wave.cuda(), want_mag=True, want_spec=True)
+    mg, sg, _ = gen.stft(wave.cuda(), want_mag=True, want_spec=True)
+    assert torch.equal(mf.reshape(2 * Tn, -1)[:, op.n_stft:], torch.zeros_like(mf.reshape(2 * Tn, -1)[:, op.n_stft:]))  # stride padding stays zero
+    xf, xg = fam.unpack_complex(sf, 2, Tn).cpu(), gen.unpack_complex(sg, 2, Tn).cpu()
+    e_or, e_gen = float((xf - ref).abs().max() / ref.abs().max()), float((xf - xg).abs().max() / ref.abs().max())
+    e_mag = float((fam.unpack_magnitudes(mf, 2, Tn).cpu() - ref.abs()).abs().max() / ref.abs().max())
+    print(f"{rate} Hz row-family STFT: rel err {e_or:.2e} vs oracle, {e_gen:.2e} vs the generic engine, magnitudes {e_mag:.2e}")
+    assert xf.shape == ref.shape and e_or <= 3e-6 and e_gen <= 3e-6 and e_mag <= 3e-6
+    mel_ref = O.mel_amplitudes_from_waveform(wave, op)
+    mel = fam.mel_from_waveform(wave.cuda()).cpu()
+    assert (mel - mel_ref).abs().max() <= 1e-4 * mel_ref.max() and torch.linalg.norm(mel - mel_ref) / torch.linalg.norm(mel_ref) <= 1e-4
     # production RNG: the two engines draw the same initial angles
     w1 = fam.griffinlim(S, B, T, 2, 0.99, seed=11).cpu()
     w2 = gen.griffinlim(S, B, T, 2, 0.99, seed=11).cpu()
