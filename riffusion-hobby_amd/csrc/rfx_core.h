@@ -430,16 +430,29 @@ RFX_HD cf gl_project(cf a, float S) {
   return cf{a.re * sc, a.im * sc};
 }
 
-// counter-based uniform [0,1) pair for the rand_init of Griffin-Lim (stand-in for torch.rand, whose
-// Philox stream cannot be reproduced bit-for-bit by construction; parity tests inject angles0).
-RFX_HD cf rand_unit_pair(unsigned long long seed, unsigned long long ctr) {
-  unsigned long long z = ctr * 0x9E3779B97F4A7C15ull + seed;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  const float a = (float)((unsigned)(z >> 40)) * (1.0f / 16777216.0f);
-  const float b = (float)((unsigned)(z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
-  return cf{a, b};
+// Counter-based uniform [0, 1) values for the random starts (Griffin-Lim's rand_init phases, the SGD's initial spectrogram):
+// stand-ins for torch.rand, whose Philox stream cannot be reproduced bit for bit by construction (parity tests inject the
+// initial values).  One 32-bit mix per value on a per-frame key.  (Rounds 1-3 ran a 64-bit splitmix per value - three 64-bit
+// multiplications, ~65 issue slots: the initial ISTFT launch cost as much as a full Griffin-Lim iteration because of it.)
+RFX_HD unsigned mix32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x21f0aaadu;
+  x ^= x >> 15;
+  x *= 0x735a2d97u;
+  x ^= x >> 15;
+  return x;
+}
+// key of frame `frame` (the global frame index b * T + t) under `seed`
+RFX_HD unsigned rand_frame_key(unsigned long long seed, unsigned long long frame) {
+  return mix32((unsigned)frame ^ mix32((unsigned)(frame >> 32) ^ (unsigned)(seed >> 32)) ^ mix32((unsigned)seed ^ 0x632BE59Bu));
+}
+RFX_HD float rand_unit(unsigned key, int f) { return (float)(mix32(((unsigned)f * 0x9E3779B9u) ^ key) >> 8) * (1.0f / 16777216.0f); }
+// (real, imaginary) of bin `bin`: the second word is drawn from the first with one more multiplication
+RFX_HD cf rand_unit_pair(unsigned key, int bin) {
+  const unsigned a = mix32(((unsigned)bin * 0x9E3779B9u) ^ key);
+  unsigned b = (a ^ 0x85EBCA6Bu) * 0xC2B2AE35u;
+  b ^= b >> 15;
+  return cf{(float)(a >> 8) * (1.0f / 16777216.0f), (float)(b >> 8) * (1.0f / 16777216.0f)};
 }
 
 // reflect-padded sample index of torch.stft(center=True, pad_mode="reflect"): position p of the

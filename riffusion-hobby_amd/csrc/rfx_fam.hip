@@ -195,14 +195,14 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
 #pragma unroll
       for (int s = 0; s < RB; ++s) R[s] = gl_project(R[s], Sv[s]);
     } else {
-      const long long clipfr = gf;
+      const unsigned rng_key = rand_frame_key(a.seed, (unsigned long long)gf);  // the generic engine's stream
 #pragma unroll
       for (int s = 0; s < RB; ++s) {
         bool cj;
         const int bin = fam_slot_bin(a.g, rowB, pB, s, &cj);
         cf ang;
-        if (a.angles0) ang = a.angles0[(size_t)clipfr * a.fs_plain + bin];
-        else ang = rand_unit_pair(a.seed, (unsigned long long)clipfr * a.g.n_stft + bin);  // the generic engine's stream
+        if (a.angles0) ang = a.angles0[(size_t)gf * a.fs_plain + bin];
+        else ang = rand_unit_pair(rng_key, bin);
         const float sv = ld1<RFX_FAM_STREAM_AUX>(S, tB4, (unsigned)s * (NT * 4u));
         R[s] = cf{sv * ang.re, cj ? -(sv * ang.im) : sv * ang.im};
       }

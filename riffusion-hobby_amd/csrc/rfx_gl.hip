@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   if (MODE != 0) load_window();
   for (int fr = t0; fr <= t1; ++fr) {
     const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
-    const unsigned long long rng_base = ((unsigned long long)clip * g.T + fr) * kBins;
+    const unsigned rng_key = rand_frame_key(g.seed, (unsigned long long)clip * g.T + fr);
 
     cf R[21];
     MagRegs mag;
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
         for (int kb = 0; kb < 21; ++kb) {
           bool cj;
           const int bin = slot_bin(t.k1, t.idx, kb, &cj);
-          const cf r = rand_unit_pair(g.seed, rng_base + bin);
+          const cf r = rand_unit_pair(rng_key, bin);
           R[kb] = cf{r.re, cj ? -r.im : r.im};
         }
       }
@@ -337,12 +337,12 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_frame_kernel(GlFra
         const v2f w = ld2<RFX_STREAM_AUX>(init, q16 >> 1, 2u * foff + 20u * kQPad * 8u);
         R[20] = cf{w.x, w.y};
       } else {
-        const unsigned long long rng_base = ((unsigned long long)clip * g.T + fr) * kBins;  // same stream as gl_iter_kernel
+        const unsigned rng_key = rand_frame_key(g.seed, (unsigned long long)clip * g.T + fr);  // same stream as gl_iter_kernel
 #pragma unroll
         for (int kb = 0; kb < 21; ++kb) {
           bool cj;
           const int bin = slot_bin(t.k1, t.idx, kb, &cj);
-          const cf r = rand_unit_pair(g.seed, rng_base + bin);
+          const cf r = rand_unit_pair(rng_key, bin);
           R[kb] = cf{r.re, cj ? -r.im : r.im};
         }
       }

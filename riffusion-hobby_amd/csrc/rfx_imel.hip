@@ -24,14 +24,6 @@ namespace rfx {
 
 constexpr int kImelThreads = 256;
 
-RFX_HD float rand_unit(unsigned long long seed, unsigned long long ctr) {
-  unsigned long long z = ctr * 0x9E3779B97F4A7C15ull + seed + 0x632BE59BD9B4E019ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)((unsigned)(z >> 40)) * (1.0f / 16777216.0f);
-}
-
 template <int BPT>  // bins per thread
 __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,7 +49,7 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
   // ---- phase-B ownership: bins f = f_lo + tid + 256*j
   float spec[BPT], buf[BPT], w0[BPT], w1[BPT];
   int m0[BPT];
-  const unsigned long long rbase = (unsigned long long)frame * n_stft;
+  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
 #pragma unroll
   for (int j = 0; j < BPT; ++j) {
     const int f = tb.f_lo + tid + kImelThreads * j;
@@ -65,7 +57,7 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
     m0[j] = ok ? tb.bin_m0[f] : -1;
     w0[j] = ok ? tb.bin_w0[f] : 0.f;
     w1[j] = ok ? tb.bin_w1[f] : 0.f;
-    spec[j] = ok ? (a.spec0 ? a.spec0[(size_t)frame * n_stft + f] : rand_unit(a.seed, rbase + f)) : 0.f;
+    spec[j] = ok ? (a.spec0 ? a.spec0[(size_t)frame * n_stft + f] : rand_unit(rbase, f)) : 0.f;
     buf[j] = 0.f;
     if (m0[j] < 0) { m0[j] = a.M; w0[j] = 0.f; w1[j] = 0.f; }  // a zero row inside the range: reads the pad, never moves
     if (ok) spec_s[f - tb.f_lo] = spec[j];
@@ -157,7 +149,7 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
   }
   for (int f = tid; f < n_stft; f += kImelThreads) {
     if (f >= tb.f_lo && f < tb.f_hi) continue;
-    const float v = a.spec0 ? a.spec0[(size_t)frame * n_stft + f] : rand_unit(a.seed, rbase + f);
+    const float v = a.spec0 ? a.spec0[(size_t)frame * n_stft + f] : rand_unit(rbase, f);
     out[tb.bin_pos[f]] = v;
     const int p2 = tb.bin_pos2[f];
     if (p2 >= 0) out[p2] = v;
@@ -252,7 +244,7 @@ struct GroupState {
 };
 
 template <int N, bool UF>
-__device__ __forceinline__ void group_load(GroupState<N, UF>& g, int grp, const ImelArgs& a, int frame, unsigned long long rbase, float scale) {
+__device__ __forceinline__ void group_load(GroupState<N, UF>& g, int grp, const ImelArgs& a, int frame, unsigned rbase, float scale) {
   const ImelTables& tb = a.tb;
   g.f0 = grp >= 0 ? tb.grp_start[grp] : 0;
   g.n = grp >= 0 ? tb.grp_start[grp + 1] - g.f0 : 0;
@@ -262,7 +254,7 @@ __device__ __forceinline__ void group_load(GroupState<N, UF>& g, int grp, const 
     const int f = g.f0 + (ok ? i : 0);
     g.w0[i] = ok ? tb.bin_w0[f] : 0.f;
     g.w1[i] = ok ? tb.bin_w1[f] : 0.f;
-    g.spec[i] = ok ? scale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(a.seed, rbase + f)) : 0.f;
+    g.spec[i] = ok ? scale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
     g.buf[i] = 0.f;
   }
 }
@@ -331,7 +323,7 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
   const int clip = b / a.C;
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass (one frame per workgroup): this clip never stopped early
-  const unsigned long long rbase = (unsigned long long)frame * a.n_stft;
+  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
 
   const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;           // long groups, counted down from the top
   const int gL = (tid < M - kImelThreads) ? tid : -1;             // short groups, counted up from 0
@@ -395,7 +387,7 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
   group_store(hi, tb, out, kUnscale);
   for (int f = tid; f < a.n_stft; f += kImelThreads) {
     if (f >= tb.f_lo && f < tb.f_hi) continue;
-    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(a.seed, rbase + f);
+    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f);
     out[tb.bin_pos[f]] = v;
     const int p2 = tb.bin_pos2[f];
     if (p2 >= 0) out[p2] = v;

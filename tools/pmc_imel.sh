@@ -9,7 +9,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_
            "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p -- python $R/tools/probe_imel.py > $OUT/p$i.log 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p -- python $R/tools/probe_imel.py > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections, json, subprocess
