@@ -135,3 +135,87 @@ int emu_fam_geom(int n_fft, int win, int hop, int* out6) {
   return 0;
 }
 }
+
+// Griffin-Lim of one clip exactly as the kernels of rfx_fam.hip + gen_fold_kernel run it (rfx_api.hip::gen_griffinlim): launch
+// 0 synthesises S * angles0, launch it >= 1 analyses x_{it-1} - m x_{it-2} (momentum applied in the time domain), projects every
+// slot, synthesises; the windowed frames are overlap-added and divided by the window envelope.  Host arithmetic (exact sqrt and
+// divide in gl_project where the device uses v_rsq_f32).
+namespace {
+template <int RA, int RB>
+int gl_run(const FamGeom& g, int T, int n_iter, float momentum, const float* mag, const float* ang, const float* win, float* out) {
+  FamTables t;
+  make_tables(g, t);
+  const int L = g.hop * (T - 1);
+  if (n_iter > 0 && L <= g.n_fft / 2) return -4;
+  const float m = momentum / (1.f + momentum);
+  std::vector<float> gen[3];
+  for (auto& v : gen) v.assign((size_t)L, 0.f);
+  std::vector<float> frames((size_t)T * g.win), u(g.win), y(g.win);
+  std::vector<cf> slots;
+  const float sc = 1.0f;  // inverse<> already applies 2 / n_fft
+  for (int it = 0; it <= n_iter; ++it) {
+    const std::vector<float>& xc = gen[(it + 2) % 3];
+    const std::vector<float>& xp = gen[(it + 1) % 3];
+    for (int fr = 0; fr < T; ++fr) {
+      if (it == 0) {
+        slots.assign((size_t)g.fsf, cf{0.f, 0.f});
+      } else {
+        for (int j = 0; j < g.win; ++j) {
+          const int p = reflect_index(g.hop * fr + j - 5 * g.h, L);
+          const float x = it >= 2 ? fmaf(-m, xp[p], xc[p]) : xc[p];
+          u[j] = x * win[j];
+        }
+        forward<RA, RB>(g, t, u.data(), slots);
+      }
+      for (int k1 = 0; k1 < kFamRows; ++k1)
+        for (int p = 0; p < RA; ++p)
+          for (int s2 = 0; s2 < RB; ++s2) {
+            bool cj;
+            const int bin = fam_slot_bin(g, k1, p, s2, &cj);
+            cf& z = slots[(size_t)s2 * g.nthr + k1 * RA + p];
+            const float S = mag[(size_t)bin * T + fr];
+            if (it == 0) {
+              const cf a{ang[2 * ((size_t)bin * T + fr)], ang[2 * ((size_t)bin * T + fr) + 1]};
+              z = cf{S * a.re, cj ? -(S * a.im) : S * a.im};
+            } else {
+              z = gl_project(z, S);
+            }
+          }
+      inverse<RA, RB>(g, t, slots, y.data());
+      for (int j = 0; j < g.win; ++j) frames[(size_t)fr * g.win + j] = y[j] * sc * win[j];
+    }
+    // gen_fold_kernel: sample p of the output sits at P = p + n_fft/2 of the padded signal; frame t contributes j = P - hop t - left
+    std::vector<float>& dst = gen[it % 3];
+    for (int p = 0; p < L; ++p) {
+      const int q = p + g.n_fft / 2 - 15 * g.h;
+      int tlo = q - (g.win - 1) <= 0 ? 0 : (q - (g.win - 1) + g.hop - 1) / g.hop;
+      int thi = q / g.hop;
+      if (thi > T - 1) thi = T - 1;
+      float acc = 0.f, env = 0.f;
+      for (int tt = tlo; tt <= thi; ++tt) {
+        const int j = q - g.hop * tt;
+        acc += frames[(size_t)tt * g.win + j];
+        env = fmaf(win[j], win[j], env);
+      }
+      dst[p] = acc / env;
+    }
+  }
+  for (int p = 0; p < L; ++p) out[p] = gen[n_iter % 3][p];
+  return 0;
+}
+}  // namespace
+
+extern "C" int emu_fam_griffinlim(int n_fft, int hop, int T, int n_iter, float momentum, const float* mag, const float* ang,
+                                  const float* win, float* out) {
+  FamGeom g;
+  if (!fam_make_geom(n_fft, n_fft / 4, hop, &g)) return -1;
+  switch (g.h) {
+    case 80: return gl_run<10, 8>(g, T, n_iter, momentum, mag, ang, win, out);
+    case 160: return gl_run<16, 10>(g, T, n_iter, momentum, mag, ang, win, out);
+    case 240: return gl_run<16, 15>(g, T, n_iter, momentum, mag, ang, win, out);
+    case 320: return gl_run<20, 16>(g, T, n_iter, momentum, mag, ang, win, out);
+    case 441: return gl_run<21, 21>(g, T, n_iter, momentum, mag, ang, win, out);
+    case 480: return gl_run<24, 20>(g, T, n_iter, momentum, mag, ang, win, out);
+  }
+  return -1;
+}

@@ -57,3 +57,33 @@ def test_geometries_outside_the_family_are_refused(emu):
     assert emu.emu_fam_geom(19200, 4000, 480, out) == -1         # window not a quarter of the frame
     assert emu.emu_fam_geom(38400, 9600, 960, out) == -1         # 96 kHz: the 21 x 960 cube exceeds the LDS of a CU
     assert emu.emu_fam_geom(3465, 866, 86, out) == -1
+
+
+@pytest.mark.parametrize("rate,hop_ms,T,n_iter", [(8000, 10, 31, 0), (8000, 10, 31, 3), (16000, 5, 45, 2)])
+def test_griffinlim_on_the_emulated_kernels_matches_the_oracle(emu, rate, hop_ms, T, n_iter):
+    """The whole loop as rfx_fam.hip + gen_fold_kernel run it (initial synthesis from S * angles0, analysis of
+    x_k - m x_{k-1}, per-slot projection incl. the conjugate and duplicate slots, pruned synthesis, overlap-add and envelope
+    division) against torchaudio's Griffin-Lim as restated by the oracle - on the CPU, before any GPU time."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import riffusion_oracle as O
+
+    op = O.OracleParams(sample_rate=rate, step_size_ms=hop_ms, max_frequency=rate // 2)
+    assert op.n_fft == 40 * (op.n_fft // 40) and op.win_length * 4 == op.n_fft
+    g = torch.Generator().manual_seed(rate + n_iter)
+    mag = torch.rand(1, op.n_stft, T, generator=g) * 1000
+    a0 = torch.rand(1, op.n_stft, T, dtype=torch.complex64, generator=g)
+    want = O.griffinlim(mag, op, angles0=a0, n_iter=n_iter)[0].numpy()
+    win = O.hann_window(op).numpy().astype(np.float32)
+    out = np.zeros(op.hop_length * (T - 1), np.float32)
+    magn = np.ascontiguousarray(mag[0].numpy())
+    angn = np.ascontiguousarray(torch.view_as_real(a0[0]).numpy())
+    rc = emu.emu_fam_griffinlim(op.n_fft, op.hop_length, T, n_iter, ctypes.c_float(0.99), magn.ctypes.data_as(FP), angn.ctypes.data_as(FP),
+                                win.ctypes.data_as(FP), out.ctypes.data_as(FP))
+    assert rc == 0 and out.shape == want.shape
+    snr = 10 * np.log10(np.sum(want.astype(np.float64) ** 2) / np.sum((want.astype(np.float64) - out) ** 2))
+    print(f"{rate} Hz, hop {op.hop_length}, T = {T}: emulated row-family Griffin-Lim n_iter={n_iter}: {snr:.1f} dB vs the oracle")
+    assert snr >= (110.0 if n_iter == 0 else 90.0)
