@@ -301,7 +301,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   }
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
   if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
-  pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : 0;
+  pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : getenv("RFX_IMEL_NO_PAIR") ? 3 : 0;  // 3: best one-frame kernel
   // which Griffin-Lim device form a call takes: the options of rfx_plan_create_ex decide; the environment (read here, once)
   // only changes what RFX_GL_FORM_AUTO / the default threshold mean, for experiments
   if (const char* e = getenv("RFX_GL_LATENCY_MODE")) pl->gl_latency_mode = atoi(e) != 0;
@@ -526,6 +526,12 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
         }
       }
     }
+    bool pair_ok = fast && fast_code == 2 && unit_form && M == 512;
+    if (pair_ok) {
+      std::vector<int> cnt2(M, 0);
+      for (int f = f_lo; f < f_hi; ++f) cnt2[bin_m0[f]]++;
+      for (int t2 = 0; t2 < 256 && pair_ok; ++t2) pair_ok = cnt2[M - 1 - t2] >= rfx::kImelHiMin[t2 >> 6];
+    }
     pl->imel_ok = ok;
     pl->imel_why = why;
     // ---- fused forward path: per-filter band tables, weights transposed so that lane m reads row i coalesced
@@ -663,6 +669,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->imel.grp_start = (const int*)(d + o_gs);
       pl->imel.fast_ok = fast ? fast_code : 0;
       pl->imel.unit_form = fast && unit_form ? 1 : 0;
+      pl->imel.pair_ok = pair_ok ? 1 : 0;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;
