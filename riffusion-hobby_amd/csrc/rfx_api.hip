@@ -832,7 +832,7 @@ static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames
   off_frames = o;
   o += align_up(nf * g.win * sizeof(float), 256);
   off_audio = o;
-  o += align_up(3 * (size_t)B * Lpad * sizeof(float), 256);
+  o += align_up((3 * (size_t)B + 1) * Lpad * sizeof(float), 256);  // + the window envelope of the fold, [Lpad]
   if (plan->fam_ok) o += align_up(nf * plan->fam.fsf * sizeof(float), 256);
   total = o;
 }
@@ -853,6 +853,8 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   float* frames = (float*)(ws + ofr);
   float* gen[3];
   for (int i = 0; i < 3; ++i) gen[i] = (float*)(ws + oa) + (size_t)i * B * Lpad;  // x_k lives in gen[k % 3]
+  float* env = (float*)(ws + oa) + (size_t)3 * B * Lpad;
+  RFX_HIP(launch_gen_env(plan->d_win, env, g, T, L, stream));
   EventList events;
   if (h_launch_ms) {
     RFX_HIP(events.create(n_iter + 2));
@@ -860,8 +862,8 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   }
   if (plan->fam_ok) {
     const FamGeom& f = plan->fam;
-    float* S_slots = (float*)(ws + oa + align_up(3 * (size_t)B * Lpad * sizeof(float), 256));
-    RFX_HIP(launch_fam_repack(d_mag, S_slots, plan->d_fam_binof, (long long)B * T, g.fs, f.fsf, stream));
+    float* S_slots = (float*)(ws + oa + align_up((3 * (size_t)B + 1) * Lpad * sizeof(float), 256));
+    RFX_HIP(launch_fam_repack(d_mag, S_slots, plan->d_fam_binof, (long long)B * T, g.fs, f.fsf, f.n_stft, stream));
     FamGlArgs fa{};
     fa.g = f;
     fa.S = S_slots;
@@ -884,7 +886,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
       fa.x_prev = gen[(it + 1) % 3];
       RFX_HIP(launch_fam_gl(it == 0 ? 0 : it == 1 ? 1 : 2, fa, nblocks, stream));
       const bool last = it == n_iter;
-      RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+      RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
       if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
     }
     if (h_launch_ms) {
@@ -912,7 +914,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     a.x_prev = gen[(it + 1) % 3];
     RFX_HIP(launch_gen_gl(it == 0 ? 0 : it == 1 ? 1 : 2, a, plan->num_cus, stream));
     const bool last = it == n_iter;
-    RFX_HIP(launch_gen_fold(frames, plan->d_win, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+    RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
     if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
   }
   if (h_launch_ms) {

@@ -302,24 +302,53 @@ gen_gl_kernel(GenGlArgs a) {
 
 // overlap-add of the windowed frames and division by the window envelope (torch.istft center=True, length = hop*(T-1)):
 // sample p of the output sits at P = p + n_fft/2 of the padded signal; frame t contributes its window sample
-// j = P - hop*t - left.  One thread per output sample, fixed summation order (t ascending): bit-reproducible.
-__global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__ frames, const float* __restrict__ win,
+// j = P - hop*t - left.  Fixed summation order (t ascending): bit-reproducible.  The envelope sum_t w[j]^2 depends on p only and
+// is computed once per call (gen_env_kernel; the fold recomputed it per sample and iteration: ten window loads and FMAs next to
+// the ten frame loads); where the geometry allows it (window, hop, left margin and lengths multiples of four: 48 kHz, 16 kHz ...)
+// a thread folds four consecutive samples with 16-byte accesses - they share their frame range.  Same arithmetic, same bits.
+__device__ __forceinline__ void gen_fold_range(const GenGeom& g, int q, int T, int& tlo, int& thi) {
+  tlo = q - (g.win - 1) <= 0 ? 0 : (q - (g.win - 1) + g.hop - 1) / g.hop;
+  thi = q / g.hop;
+  if (thi > T - 1) thi = T - 1;
+}
+__global__ void __launch_bounds__(256) gen_env_kernel(const float* __restrict__ win, float* __restrict__ env, GenGeom g, int T, int L) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= L) return;
+  const int q = p + g.n_fft / 2 - g.left;  // j = q - hop*t
+  int tlo, thi;
+  gen_fold_range(g, q, T, tlo, thi);
+  float e = 0.f;
+  for (int t = tlo; t <= thi; ++t) {
+    const float w = win[q - g.hop * t];
+    e = fmaf(w, w, e);
+  }
+  env[p] = e;
+}
+__global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__ frames, const float* __restrict__ env,
                                                        float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (p >= L) return;
-  const int q = p + g.n_fft / 2 - g.left;  // j = q - hop*t
-  int tlo = q - (g.win - 1) <= 0 ? 0 : (q - (g.win - 1) + g.hop - 1) / g.hop;
-  int thi = q / g.hop;
-  if (thi > T - 1) thi = T - 1;
-  float acc = 0.f, env = 0.f;
-  for (int t = tlo; t <= thi; ++t) {
-    const int j = q - g.hop * t;
-    const float w = win[j];
-    acc += frames[((size_t)b * T + t) * g.win + j];
-    env = fmaf(w, w, env);
-  }
-  out[(size_t)b * out_stride + p] = acc / env;
+  const int q = p + g.n_fft / 2 - g.left;
+  int tlo, thi;
+  gen_fold_range(g, q, T, tlo, thi);
+  float acc = 0.f;
+  for (int t = tlo; t <= thi; ++t) acc += frames[((size_t)b * T + t) * g.win + (q - g.hop * t)];
+  out[(size_t)b * out_stride + p] = acc / env[p];
+}
+__global__ void __launch_bounds__(256) gen_fold4_kernel(const float* __restrict__ frames, const float* __restrict__ env,
+                                                        float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride) {
+  using v4 = float __attribute__((ext_vector_type(4)));
+  const int p = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const int b = blockIdx.y;
+  if (p >= L) return;
+  const int q = p + g.n_fft / 2 - g.left;  // a multiple of four, like hop: q .. q + 3 share their frame range
+  int tlo, thi;
+  gen_fold_range(g, q, T, tlo, thi);
+  v4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = tlo; t <= thi; ++t) acc += *reinterpret_cast<const v4*>(frames + ((size_t)b * T + t) * g.win + (q - g.hop * t));
+  const v4 e = *reinterpret_cast<const v4*>(env + p);
+  *reinterpret_cast<v4*>(out + (size_t)b * out_stride + p) = v4{acc.x / e.x, acc.y / e.y, acc.z / e.z, acc.w / e.w};
 }
 
 // ---- (B, F, T) <-> [B*T][fs] layout conversion (tiled transposes; the padding of the frame stride is zeroed)
@@ -442,9 +471,16 @@ hipError_t launch_gen_gl(int mode, const GenGlArgs& a, int num_cus, hipStream_t 
   return hipGetLastError();
 }
 
-hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
+hipError_t launch_gen_env(const float* win, float* env, const GenGeom& g, int T, int L, hipStream_t stream) {
+  hipLaunchKernelGGL(gen_env_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, win, env, g, T, L);
+  return hipGetLastError();
+}
+hipError_t launch_gen_fold(const float* frames, const float* env, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, win, out, g, B, T, L, out_stride);
+  const bool vec = g.win % 4 == 0 && g.hop % 4 == 0 && (g.n_fft / 2 - g.left) % 4 == 0 && L % 4 == 0 && out_stride % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(env) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(gen_fold4_kernel, dim3((L / 4 + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride);
+  else hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride);
   return hipGetLastError();
 }
 

@@ -198,7 +198,8 @@ hipError_t prepare_generic_kernels(const GenGeom& g);
 size_t gen_lds_bytes(const GenGeom& g);
 hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStream_t stream);  // mode 0 mag, 1 spec
 hipError_t launch_gen_gl(int mode, const GenGlArgs& a, int num_cus, hipStream_t stream);      // mode 0 init, 1 first iteration, 2 iteration
-hipError_t launch_gen_fold(const float* frames, const float* win, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
+hipError_t launch_gen_env(const float* win, float* env, const GenGeom& g, int T, int L, hipStream_t stream);  // env[p] = sum_t w[j]^2, once per call
+hipError_t launch_gen_fold(const float* frames, const float* env, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
                            hipStream_t stream);  // L output samples per clip
 hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
@@ -244,7 +245,8 @@ size_t fam_static_lds_bytes(const FamGeom& g);  // static: the pass-A twiddles w
 int fam_blocks_per_cu(const FamGeom& g);
 bool fam_row_stride_even(const FamGeom& g);     // the kernels use 16-byte LDS accesses in pass B: rows must start 16-byte aligned
 hipError_t launch_fam_gl(int mode, const FamGlArgs& a, int nblocks, hipStream_t stream);  // mode 0 init, 1 first iteration, 2 iteration
-hipError_t launch_fam_repack(const float* plain, float* slots, const int* bin_of, long long nframes, int fs_plain, int fsf, hipStream_t stream);
+hipError_t launch_fam_repack(const float* plain, float* slots, const int* bin_of, long long nframes, int fs_plain, int fsf, int n_stft,
+                             hipStream_t stream);
 
 // image / PCM codecs
 hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out, int N, int H, int W, int C, hipStream_t s);
