@@ -42,6 +42,9 @@ constexpr int fam_threads(int ra, int rb) {
 #ifndef RFX_FAM_TW_EARLY
 #define RFX_FAM_TW_EARLY 0
 #endif
+#ifndef RFX_FAM_STORE_AUX
+#define RFX_FAM_STORE_AUX 0  // cache policy of the synthesis-frame stores (the fold reads them back once)
+#endif
 #ifndef RFX_FAM_STREAM_AUX
 #define RFX_FAM_STREAM_AUX kAuxNT  // |S| is read once per iteration: streamed past L2
 #endif
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
       if (act1) {
         const rsrc_t out = make_rsrc(a.frames + (size_t)gf * a.g.win, (size_t)10 * H * sizeof(float));
 #pragma unroll
-        for (int j = 0; j < 10; ++j) st1(y[j] * (wv[j] * oscale), out, npr4, (unsigned)j * (H * 4u));
+        for (int j = 0; j < 10; ++j) st1<RFX_FAM_STORE_AUX>(y[j] * (wv[j] * oscale), out, npr4, (unsigned)j * (H * 4u));
       }
     }
     RFX_SCHED_FENCE();
