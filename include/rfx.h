@@ -43,9 +43,9 @@ typedef enum {
  * already resolved to samples (spectrogram_params.py:62-81). */
 typedef struct {
   int32_t sample_rate;
-  int32_t n_fft;        /* 17640 at 44.1 kHz: that geometry (with win 4410, hop 441) runs on the specialised engine, */
-  int32_t win_length;   /* 4410     every other one (48 kHz: 19200 / 4800 / 480, 22.05 kHz: 8820 / 2205 / 220, ...) on */
-  int32_t hop_length;   /* 441      the generic mixed-radix engine: same entry points and semantics   */
+  int32_t n_fft;        /* 17640 at 44.1 kHz: that geometry (with win 4410, hop 441) runs on the specialised engine; n_fft = 40 h, */
+  int32_t win_length;   /* 4410     win = 10 h with h in {80 .. 480} (48 kHz: 19200 / 4800 / 480, 32, 24, 16, 8 kHz) on the row-family   */
+  int32_t hop_length;   /* 441      kernels, every other one (22.05 kHz: 8820 / 2205 / 220, ...) on the generic engine (4.5) */
   int32_t n_mels;       /* num_frequencies */
   int32_t max_mel_iters;
 } rfx_params;
@@ -57,9 +57,11 @@ int rfx_frame_stride(void);   /* of the default 44.1 kHz geometry; per plan: rfx
 int rfx_num_bins(void);
 /* frame stride of THIS plan's slot arrays (generic-geometry plans store plain bin-ordered frames, n_stft rounded up to 64) */
 int rfx_plan_frame_stride(const rfx_plan* plan);
-/* 1 when the plan runs on the generic engine (any geometry but 17640 / 4410 / 441): an in-place mixed-radix FFT (digits up to 16,
- * exact per-pass twiddles) in LDS, Griffin-Lim fused per frame with the momentum applied in the time domain - the same
- * formulation as the specialised engine, two launches per iteration; measured 1.9-3.3x slower per tile */
+/* 1 when the plan is a generic-geometry plan (any geometry but 17640 / 4410 / 441): plain bin-ordered frames, and either the
+ * row-family kernels (n_fft = 40 h, win = 10 h: the specialised engine's factorisation, 1.7x its per-tile time at 48 kHz) or the
+ * generic engine - an in-place mixed-radix FFT (digits up to 16, exact per-pass twiddles) in LDS - for Griffin-Lim and the
+ * forward STFT (rfx_plan_griffinlim_engine says which); Griffin-Lim is fused per frame with the momentum applied in the time
+ * domain, two launches per iteration, on both */
 int rfx_plan_is_generic(const rfx_plan* plan);
 
 /* Builds the device constants that spectrogram_converter.py:47-99 builds as torchaudio module
