@@ -166,7 +166,7 @@ int rfx_plan_is_generic(const rfx_plan* plan) { return plan && plan->generic ? 1
 int rfx_plan_griffinlim_engine(const rfx_plan* plan) { return !plan ? -1 : !plan->generic ? 0 : plan->fam_ok ? 2 : 1; }
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
 int rfx_plan_imel_unit_form(const rfx_plan* plan) {
-  if (!plan || !plan->d_melfb || !plan->imel_ok || plan->imel_variant != 0) return 0;
+  if (!plan || !plan->d_melfb || !plan->imel_ok || (plan->imel_variant != 0 && plan->imel_variant != 3)) return 0;
   return plan->imel.fast_ok >= 2 ? plan->imel.unit_form : 0;
 }
 
