@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
       for (int s = 0; s < RB; ++s) {
         bool cj;
         const int bin = fam_slot_bin(a.g, rowB, pB, s, &cj);
-        if (!cj || (rowB != 0 && rowB != 20)) {  // rows 0 and 20 hold their bins twice: the direct slot writes
+        if (fam_slot_is_primary(rowB, cj)) {  // rows 0 and 20 hold their bins twice: the direct slot writes
           if (MODE == 1) cube[bin] = cf{R[s].re, cj ? -R[s].im : R[s].im};
           // v_sqrt_f32 (1 ulp) instead of the IEEE expansion: |X| carries ~1e-7 relative error from the transform anyway
           else magl[bin] = __builtin_amdgcn_sqrtf(fmaf(R[s].re, R[s].re, R[s].im * R[s].im));

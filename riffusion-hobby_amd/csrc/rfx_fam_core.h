@@ -76,6 +76,10 @@ RFX_HD int fam_slot_bin(const FamGeom& g, int k1, int p, int s, bool* conj_out) 
 // complex product for the rows 11..19 instead of nine more table loads per frame and eighteen registers
 RFX_HD cf fam_g_pow(const cf (&w)[12], int k) { return k <= 10 ? w[k] : k == 20 ? w[11] : cmulc(w[11], w[20 - k]); }
 
+// Which slot writes a bin when the frame leaves in bin order (forward kernel): bins with k mod 40 in 21..39 exist as a conjugate
+// slot only, bins on rows 0 and 20 exist twice (the slot k and the slot n_fft - k): the direct one writes
+RFX_HD bool fam_slot_is_primary(int k1, bool conj) { return !conj || (k1 != 0 && k1 != 20); }
+
 // ---- P1: thread n' < h.  tw1(k1) = g(n')^k1
 template <class TW>
 RFX_HD void fam_p1_forward_store(const float (&u)[10], TW tw1, cf* cube, int npr, int rs) {

@@ -128,6 +128,20 @@ int emu_fam_transform(int n_fft, int dir, int rs_pad, const float* in, float* ou
   }
   return -1;
 }
+// how many primary slots (fam_slot_is_primary: the forward kernel's writers) each one-sided bin has: must be exactly one
+int emu_fam_primary_writers(int n_fft, int* count /* [n_fft / 2 + 1] */) {
+  FamGeom g;
+  if (!fam_make_geom(n_fft, n_fft / 4, n_fft / 40, &g)) return -1;
+  for (int b = 0; b < g.n_stft; ++b) count[b] = 0;
+  for (int k1 = 0; k1 < kFamRows; ++k1)
+    for (int p = 0; p < g.ra; ++p)
+      for (int s = 0; s < g.rb; ++s) {
+        bool cj;
+        const int bin = fam_slot_bin(g, k1, p, s, &cj);
+        if (fam_slot_is_primary(k1, cj)) count[bin]++;
+      }
+  return 0;
+}
 int emu_fam_geom(int n_fft, int win, int hop, int* out6) {
   FamGeom g;
   if (!fam_make_geom(n_fft, win, hop, &g)) return -1;

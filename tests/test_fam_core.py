@@ -49,6 +49,16 @@ def test_forward_and_inverse_match_numpy(emu, rate, rs_pad):
     assert np.abs(back - want).max() / np.abs(want).max() < 2e-6
 
 
+@pytest.mark.parametrize("rate", RATES)
+def test_every_bin_has_exactly_one_primary_slot(emu, rate):
+    """The forward kernel re-orders a frame through LDS: every one-sided bin must be written by exactly one slot (bins on rows
+    0 and 20 exist twice, bins with k mod 40 in 21..39 only as a conjugate slot)."""
+    n_fft = int(0.4 * rate)
+    count = np.zeros(n_fft // 2 + 1, np.int32)
+    assert emu.emu_fam_primary_writers(n_fft, count.ctypes.data_as(IP)) == 0
+    assert np.array_equal(count, np.ones_like(count))
+
+
 def test_geometries_outside_the_family_are_refused(emu):
     out = (ctypes.c_int * 6)()
     assert emu.emu_fam_geom(19200, 4800, 480, out) == 0 and list(out)[:4] == [480, 24, 20, 512]
