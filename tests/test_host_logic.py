@@ -426,3 +426,21 @@ def test_bench_gpus_flag_relaunches_n_ranks(repo_root, monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 17
+
+
+def test_plan_options_are_validated_before_any_device_call(repo_root):
+    """rfx_plan_options as the Python layer fills it: unknown gl_form / frame_engine names are refused on the host, and the
+    structure keeps the layout include/rfx.h declares (struct_size first, int32 fields after it)."""
+    import ctypes
+
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    assert [f[0] for f in _hip.RfxPlanOptions._fields_] == ["struct_size", "gl_form", "gl_frames_per_slot", "frame_engine"]
+    assert ctypes.sizeof(_hip.RfxPlanOptions) == 16
+    assert _hip.FRAME_ENGINES == {"auto": 0, "generic": 1} and _hip.GL_FORMS == {"auto": 0, "runs": 1, "frames": 2}
+    header = open(os.path.join(repo_root, "include", "rfx.h")).read()
+    assert "RFX_ENGINE_AUTO = 0" in header and "RFX_ENGINE_GENERIC = 1" in header and "int32_t frame_engine;" in header
+    for kw in ({"gl_form": "sometimes"}, {"frame_engine": "fastest"}):
+        with pytest.raises(ValueError):
+            _hip.Plan(SpectrogramParams(sample_rate=48000), "cpu", **kw)
