@@ -1,5 +1,5 @@
 // rfx_fam.hip - Griffin-Lim (torchaudio.transforms.GriffinLim as constructed at riffusion/spectrogram_converter.py:62-73,
-// called at :204) for the ROW FAMILY of STFT geometries: n_fft = 40 h, win_length = 10 h, any hop - the reference's default
+// called at :204) and the forward STFT (Spectrogram(power=None), :47-59, :179; fam_fwd_kernel below) for the ROW FAMILY of STFT geometries: n_fft = 40 h, win_length = 10 h, any hop - the reference's default
 // 400 / 100 / 10 ms (spectrogram_params.py:24-27, :62-81) at 48, 32, 24, 16 and 8 kHz (cli.py:43 takes the sample rate from
 // the input file).  Round 2 / 3 ran these on the generic engine (rfx_generic.hip: a complex FFT of n_fft / 2 points over a
 // runtime digit list, eleven barrier-separated phases per frame, 587 tiles/s at 48 kHz against 1960 at 44.1 kHz); here they
