@@ -62,9 +62,70 @@ constexpr int kCubeElems = 20 * kRowStride + kHop;
 constexpr int kWaves = RFX_WAVES;
 constexpr int kThreads = 64 * kWaves;
 
+// Packed fp32 butterflies on the device (round 4): a translation unit opts in with `#define RFX_PK 1` ahead of this header
+// (rfx_gl.hip, rfx_stft.hip; -DRFX_NO_PK builds the plain forms for A/B runs).  The generic engine stays plain: the packed
+// complex product's aligned output pair costs it registers it does not have (0 -> 180..800 B of scratch, measured in the ISA).
+#if defined(RFX_NO_PK)
+#undef RFX_PK
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RFX_PK)
+// ---- packed fp32: a complex value is an aligned VGPR pair (re, im) and a butterfly step is one v_pk_*_f32 - half the
+// issue slots of the plain form for the same ALU cycles, so a wave that is alone in being ready on its SIMD issues twice
+// the work per slot (tools/ubench/valu.hip: one wave per SIMD 2.59 ns per v_pk_fma against 2.40 ns per v_fma).  The
+// compiler matches broadcasts and whole-vector negation from vector code but not the VOP3P source selects that swap or
+// negate halves (it builds the swapped pair with v_mov): those forms are inline asm.  Semantics checked against the plain
+// forms on the device by tools/ubench/pkdft.hip.
+using c2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c2 pk_of(cf a) { return c2{a.re, a.im}; }
+__device__ __forceinline__ cf pk_to(c2 a) { return cf{a.x, a.y}; }
+__device__ __forceinline__ c2 pk_bc(float c) { return c2{c, c}; }
+__device__ __forceinline__ c2 pk_fma(c2 a, c2 b, c2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ c2 pk_add_i(c2 a, c2 b) { c2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }  // a + i b
+__device__ __forceinline__ c2 pk_sub_i(c2 a, c2 b) { c2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }  // a - i b
+#define RFX_PK_ADD(name, mods) \
+  __device__ __forceinline__ c2 name(c2 a, c2 b) { c2 r; asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b)); return r; }
+RFX_PK_ADD(pk_add_cj, "neg_hi:[0,1]")                                                  // a + conj(b)
+RFX_PK_ADD(pk_sub_cj, "neg_lo:[0,1]")                                                  // a - conj(b)
+RFX_PK_ADD(pk_cj_sub, "neg_lo:[0,1] neg_hi:[1,0]")                                     // conj(a - b)
+RFX_PK_ADD(pk_cj_add_i, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]")      // conj(a + i b)
+RFX_PK_ADD(pk_add_sw, "op_sel:[0,1] op_sel_hi:[1,0]")                                  // (a.re + b.im, a.im + b.re)
+RFX_PK_ADD(pk_sub_sw, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")        // (a.re - b.im, a.im - b.re)
+// complex products as ONE two-instruction statement: hipcc pads an asm statement whose input the preceding VALU has just
+// written with an s_nop (it cannot see that no hazard exists), so the dependent pair must not be two statements
+__device__ __forceinline__ c2 pk_cmul(c2 a, c2 w) {  // a * w = a.re * (w.re, w.im) + a.im * (-w.im, w.re)
+  c2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=&v"(r) : "v"(a), "v"(w));
+  return r;
+}
+__device__ __forceinline__ c2 pk_cmulc(c2 a, c2 w) {  // a * conj(w) = a.re * (w.re, -w.im) + a.im * (w.im, w.re)
+  c2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+      : "=&v"(r) : "v"(a), "v"(w));
+  return r;
+}
+// a -+ i q d with the real constant q in the low half of an SGPR pair (both result halves read it)
+__device__ __forceinline__ c2 pk_fma_sub_i(c2 a, float q, c2 d) {  // a - i q d = (a.re + q d.im, a.im - q d.re)
+  c2 r;
+  const unsigned long long qq = __builtin_bit_cast(unsigned, q);
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(d), "s"(qq), "v"(a));
+  return r;
+}
+__device__ __forceinline__ c2 pk_fma_add_i(c2 a, float q, c2 d) {  // a + i q d = (a.re - q d.im, a.im + q d.re)
+  c2 r;
+  const unsigned long long qq = __builtin_bit_cast(unsigned, q);
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(d), "s"(qq), "v"(a));
+  return r;
+}
+__device__ __forceinline__ cf cmul(cf a, cf b) { return pk_to(pk_cmul(pk_of(a), pk_of(b))); }
+__device__ __forceinline__ cf cmulc(cf a, cf b) { return pk_to(pk_cmulc(pk_of(a), pk_of(b))); }
+#else
 RFX_HD cf cmul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 // a * conj(b)
 RFX_HD cf cmulc(cf a, cf b) { return cf{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Slot <-> HBM position.  A P3 thread q = k1*21 + ka (0..440) owns kb = 0..20; in memory it sits
@@ -156,8 +217,54 @@ RFX_HD void dft7(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, cf& x5, cf& x6) {
 
 // 21-point DFT, natural order in and out, prime-factor (Good-Thomas) 3 x 7: no internal twiddles.
 //   input  n = (7*n1 + 3*n2) mod 21,   output k = (7*k1 + 15*k2) mod 21
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RFX_PK)
+template <bool INV>
+__device__ __forceinline__ void pk_dft3(c2& x0, c2& x1, c2& x2) {
+  const float q = INV ? -0.86602540378443864676f : 0.86602540378443864676f;
+  const c2 s = x1 + x2, d = x1 - x2;
+  const c2 a = pk_fma(pk_bc(-0.5f), s, x0);
+  x0 = x0 + s;
+  x1 = pk_fma_sub_i(a, q, d);
+  x2 = pk_fma_add_i(a, q, d);
+}
+template <bool INV>
+__device__ __forceinline__ void pk_dft7(c2& x0, c2& x1, c2& x2, c2& x3, c2& x4, c2& x5, c2& x6) {
+  constexpr float c1 = 0.62348980185873353053f, c2_ = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+  constexpr float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+  const c2 p1 = x1 + x6, m1 = x1 - x6, p2 = x2 + x5, m2 = x2 - x5, p3 = x3 + x4, m3 = x3 - x4;
+  const c2 a1 = pk_fma(pk_bc(c3), p3, pk_fma(pk_bc(c2_), p2, pk_fma(pk_bc(c1), p1, x0)));
+  const c2 a2 = pk_fma(pk_bc(c1), p3, pk_fma(pk_bc(c3), p2, pk_fma(pk_bc(c2_), p1, x0)));
+  const c2 a3 = pk_fma(pk_bc(c2_), p3, pk_fma(pk_bc(c1), p2, pk_fma(pk_bc(c3), p1, x0)));
+  const c2 b1 = pk_fma(pk_bc(s3), m3, pk_fma(pk_bc(s2), m2, pk_bc(s1) * m1));
+  const c2 b2 = pk_fma(pk_bc(-s1), m3, pk_fma(pk_bc(-s3), m2, pk_bc(s2) * m1));
+  const c2 b3 = pk_fma(pk_bc(s2), m3, pk_fma(pk_bc(-s1), m2, pk_bc(s3) * m1));
+  x0 = x0 + p1 + p2 + p3;
+  if (INV) {
+    x1 = pk_add_i(a1, b1); x6 = pk_sub_i(a1, b1); x2 = pk_add_i(a2, b2); x5 = pk_sub_i(a2, b2); x3 = pk_add_i(a3, b3); x4 = pk_sub_i(a3, b3);
+  } else {
+    x1 = pk_sub_i(a1, b1); x6 = pk_add_i(a1, b1); x2 = pk_sub_i(a2, b2); x5 = pk_add_i(a2, b2); x3 = pk_sub_i(a3, b3); x4 = pk_add_i(a3, b3);
+  }
+}
+#endif
+
 template <bool INV>
 RFX_HD void dft21(cf (&x)[21]) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RFX_PK)
+  c2 p[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) p[i] = c2{x[i].re, x[i].im};
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) pk_dft3<INV>(p[(3 * n2) % 21], p[(7 + 3 * n2) % 21], p[(14 + 3 * n2) % 21]);
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1)
+    pk_dft7<INV>(p[(7 * k1) % 21], p[(7 * k1 + 3) % 21], p[(7 * k1 + 6) % 21], p[(7 * k1 + 9) % 21],
+                 p[(7 * k1 + 12) % 21], p[(7 * k1 + 15) % 21], p[(7 * k1 + 18) % 21]);
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) x[(7 * k1 + 15 * k2) % 21] = cf{p[(7 * k1 + 3 * k2) % 21].x, p[(7 * k1 + 3 * k2) % 21].y};
+  return;
+#endif
 #pragma unroll
   for (int n2 = 0; n2 < 7; ++n2) dft3<INV>(x[(3 * n2) % 21], x[(7 + 3 * n2) % 21], x[(14 + 3 * n2) % 21]);
 #pragma unroll
@@ -250,6 +357,16 @@ RFX_HD void p1_forward_rows(const float (&u)[10], PUT put) {
     const float oei = -fmaf(S40[(9 * k) % 40], o4, fmaf(S40[(5 * k) % 40], o2, S40[k % 40] * o0));
     const float oor = fmaf(C40[(7 * k) % 40], o3, C40[(3 * k) % 40] * o1);
     const float ooi = -fmaf(S40[(7 * k) % 40], o3, S40[(3 * k) % 40] * o1);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RFX_PK)
+    {  // the same four outputs on (re, im) pairs: E = Ee + Eo, O = Oe + Oo, F' = Ee - Eo, D = Oe - Oo
+      const c2 ee{eer, eei}, eo{eor, eoi}, oe{oer, oei}, oo{oor, ooi};
+      const c2 E = ee + eo, O = oe + oo, Fp = ee - eo, D = oe - oo;
+      put(k, pk_to(E + O));
+      put(20 - k, pk_to(pk_cj_sub(E, O)));
+      put(10 - k, pk_to(pk_cj_add_i(Fp, D)));  // conj(F') + (-i) conj(D) = conj(F' + i D)
+      put(10 + k, pk_to(pk_sub_i(Fp, D)));     // conj(conj(F') - (-i) conj(D)) = F' - i D
+    }
+#else
     const float Er = eer + eor, Ei = eei + eoi, Or = oer + oor, Oi = oei + ooi;  // E[k], O[k]
     put(k, cf{Er + Or, Ei + Oi});
     put(20 - k, cf{Er - Or, -(Ei - Oi)});
@@ -259,6 +376,7 @@ RFX_HD void p1_forward_rows(const float (&u)[10], PUT put) {
     const float Gr = -di, Gi = -dr;
     put(10 - k, cf{Fr + Gr, Fi + Gi});
     put(10 + k, cf{Fr - Gr, -(Fi - Gi)});
+#endif
     RFX_SCHED_FENCE();
   }
 }
@@ -313,12 +431,19 @@ RFX_HD void p1_inverse_rows(RAW raw, FIX fix, float (&y)[10]) {
     }
     RFX_SCHED_FENCE();
     const cf Vk = fix(k, r0), Vm = fix(20 - k, r1), Wk = fix(10 - k, r2), Wm = fix(10 + k, r3);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RFX_PK)
+    const c2 pBk = pk_add_cj(pk_of(Vk), pk_of(Vm)), pDk = pk_sub_cj(pk_of(Vk), pk_of(Vm));
+    const c2 pBn = pk_add_cj(pk_of(Wk), pk_of(Wm)), pDn = pk_sub_cj(pk_of(Wk), pk_of(Wm));
+    const cf Ge = pk_to(pk_add_cj(pBk, pBn)), He = pk_to(pk_sub_cj(pBk, pBn));
+    const cf Go = pk_to(pk_sub_sw(pDk, pDn)), Ho = pk_to(pk_add_sw(pDk, pDn));
+#else
     const cf Bk{Vk.re + Vm.re, Vk.im - Vm.im}, Dk{Vk.re - Vm.re, Vk.im + Vm.im};      // B[k], D[k]
     const cf Bn{Wk.re + Wm.re, Wk.im - Wm.im}, Dn{Wk.re - Wm.re, Wk.im + Wm.im};      // B[10-k], D[10-k]
     const cf Ge{Bk.re + Bn.re, Bk.im - Bn.im}, He{Bk.re - Bn.re, Bk.im + Bn.im};      // B[k] +- conj(B[10-k])
     // (-i) * conj(x + i y) = -y - i x
     const float qr = -Dn.im, qi = -Dn.re;
     const cf Go{Dk.re + qr, Dk.im + qi}, Ho{Dk.re - qr, Dk.im - qi};                  // D[k] +- (-i) conj(D[10-k])
+#endif
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
       const cf ze = (p & 1) ? He : Ge;
@@ -427,7 +552,11 @@ RFX_HD cf gl_project(cf a, float S) {
   const float mag = sqrtf(fmaf(a.re, a.re, a.im * a.im));
   const float sc = S / (mag + 1e-16f);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RFX_PK)
+  return pk_to(pk_of(a) * pk_bc(sc));
+#else
   return cf{a.re * sc, a.im * sc};
+#endif
 }
 
 // Counter-based uniform [0, 1) values for the random starts (Griffin-Lim's rand_init phases, the SGD's initial spectrogram):

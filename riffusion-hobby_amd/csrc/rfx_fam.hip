@@ -15,6 +15,9 @@
 // iteration, same buffers and same random stream as the generic engine, which remains the fallback for every other geometry.
 // |S| arrives in the plan's plain bin-ordered layout and is re-ordered ONCE per call into slot order (thread t's slot s at
 // s * nthr + t: every wave-wide load is whole lines); duplicate slots get the same magnitude.
+#if defined(RFX_FAM_PK) && !defined(RFX_PK)
+#define RFX_PK 1  // A/B switch: packed fp32 butterflies in the row-family kernels (rfx_core.h)
+#endif
 #include <hip/hip_runtime.h>
 
 #include "rfx_fam_core.h"

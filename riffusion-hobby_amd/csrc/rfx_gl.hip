@@ -23,6 +23,7 @@
 // only cross-workgroup traffic is the 9-block halo at each end of a run.  Halo blocks are never
 // combined with atomics: run r writes its partial sums to the parity-(r&1) audio buffer and the
 // reader adds the two parity buffers, which keeps results bit-reproducible run to run.
+#define RFX_PK 1  // packed fp32 butterflies (rfx_core.h)
 #include "rfx_frame.hip.h"
 #include "rfx_kernels.h"
 

@@ -1,6 +1,7 @@
 // rfx_stft.hip - forward framed transform (replaces torchaudio.transforms.Spectrogram(power=None) +
 // torch.abs, riffusion/spectrogram_converter.py:47-59, :179-182) and the layout converters between
 // the reference's (B, n_stft, T) tensors and the slot-major frames the gfx950 kernels stream.
+#define RFX_PK 1  // packed fp32 butterflies (rfx_core.h)
 #include "rfx_frame.hip.h"
 #include "rfx_kernels.h"
 
