@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--global-clips", type=int, default=512, help="decode-stereo64: clips in the sharded batch")
     ap.add_argument("--no-forward", action="store_true", help="skip the embedded configs[2] forward measurement")
     ap.add_argument("--no-other-rates", action="store_true", help="skip the embedded 48 kHz decode measurement (row-family Griffin-Lim engine)")
+    ap.add_argument("--host-input", action="store_true",
+                    help="decode-stereo64: the timed calls take the tiles from HOST memory (the reference's API is host images in, host "
+                         "audio out); uploads run chunk by chunk through pinned memory on a side stream (batch_shard.ChunkSource)")
     ap.add_argument("--gather", choices=["none", "rank0", "all"], default="none",
                     help="decode-stereo64: which clips a rank returns (own shard / everything on rank 0 / everything everywhere)")
     return ap.parse_args()
@@ -348,7 +351,9 @@ def stereo64_main(args, world, rank, dev, distributed):
     conv = SpectrogramImageConverter(params, device=str(dev))
     N = args.global_clips
     rng = np.random.default_rng(20240807)  # the SAME full batch on every rank
-    tiles = torch.from_numpy(rng.integers(0, 256, size=(N, N_MELS, N_FRAMES, 3), dtype=np.uint8)).to(dev)
+    tiles_host = rng.integers(0, 256, size=(N, N_MELS, N_FRAMES, 3), dtype=np.uint8)  # pageable, as a caller's array would be
+    tiles = torch.from_numpy(tiles_host).to(dev)
+    timed_input = tiles_host if args.host_input else tiles
     group = dist.group.WORLD if distributed else None
     L = HOP * (N_FRAMES - 1)
 
@@ -359,11 +364,11 @@ def stereo64_main(args, world, rank, dev, distributed):
         torch.cuda.synchronize(dev)
 
     for w in range(args.warmup):
-        conv.audio_from_spectrogram_images(tiles, seed=w, group=group, gather=args.gather)  # same shapes as the timed steps (pinned blocks cached)
+        conv.audio_from_spectrogram_images(timed_input, seed=w, group=group, gather=args.gather)  # same shapes as the timed steps (pinned blocks cached)
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        pcm = conv.audio_from_spectrogram_images(tiles, seed=100 + k, group=group, gather=args.gather)
+        pcm = conv.audio_from_spectrogram_images(timed_input, seed=100 + k, group=group, gather=args.gather)
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -389,6 +394,7 @@ def stereo64_main(args, world, rank, dev, distributed):
     n_mine = myhi - mylo
     compute_ms = wall(lambda: conv.audio_from_spectrogram_images(tiles, seed=7, group=group, gather="none", return_device=True))
     host_ms = wall(lambda: conv.audio_from_spectrogram_images(tiles, seed=7, group=group, gather="none"))
+    host_in_ms = wall(lambda: conv.audio_from_spectrogram_images(tiles_host, seed=7, group=group, gather="none"))
     shard = torch.zeros((n_mine, L, 2), dtype=torch.int16, device=dev)
     pinned = torch.empty(shard.shape, dtype=torch.int16, pin_memory=True)
     d2h_raw_ms = wall(lambda: pinned.copy_(shard, non_blocking=True))
@@ -407,16 +413,20 @@ def stereo64_main(args, world, rank, dev, distributed):
     pcm_mb = N * L * 2 * 2 / 1e6
     stages = {"compute_ms": round(compute_ms, 3), "compute_plus_d2h_ms": round(host_ms, 3),
               "d2h_exposed_ms": round(max(0.0, host_ms - compute_ms), 3),
+              "host_in_host_out_ms": round(host_in_ms, 3), "h2d_exposed_ms": round(max(0.0, host_in_ms - host_ms), 3),
+              "own_shard_in_mb": round(n_mine * N_MELS * N_FRAMES * 3 / 1e6, 1),
               "d2h_own_shard_raw_ms": round(d2h_raw_ms, 3), "own_shard_mb": round(n_mine * L * 4 / 1e6, 1), **{k: round(v, 3) for k, v in gather_ms.items()},
               "note": "rank 0, best of 2, wall clock between device syncs: compute = own shard with return_device=True; compute_plus_d2h = the same "
-                      "call returning host PCM (chunk copies on a side stream behind the compute, pinned memory); d2h_own_shard_raw = the whole "
+                      "call returning host PCM (chunk copies on a side stream behind the compute, pinned memory); host_in_host_out = the same call "
+                      "fed from a pageable HOST array (uploads staged through pinned memory on a side stream, chunk k+1 under chunk k); d2h_own_shard_raw = the whole "
                       "shard in one un-overlapped pinned copy; collectives move the own shard (int16, as bytes) into one preallocated tensor"}
     out = {
         "metric": "stereo_spectrogram_tiles_per_sec_griffinlim64", "value": round(tiles_per_s, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} synthetic stereo 512x512 uint8 tiles -> image decode -> InverseMelScale SGD-200 -> Griffin-Lim 64 "
-                               f"-> int16 PCM in host memory (BASELINE.json configs[3]), clips sharded over the ranks with shard_range, gather={args.gather!r}"
+                               f"-> int16 PCM in host memory (BASELINE.json configs[3]), tiles {'in HOST memory' if args.host_input else 'resident in HBM'} when the timed region starts, "
+                               f"clips sharded over the ranks with shard_range, gather={args.gather!r}"
                                + {"none": " (every rank returns its own clips; no data-path collective)",
                                   "rank0": f" (one RCCL gather of {pcm_mb:.0f} MB int16 PCM to rank 0)",
                                   "all": f" (one RCCL all_gather_into_tensor of {pcm_mb:.0f} MB int16 PCM)"}[args.gather],

@@ -86,13 +86,24 @@ typedef enum {
   RFX_ENGINE_GENERIC = 1  /* always the generic FFT engine (cross-checks) */
 } rfx_frame_engine;
 
-/* Plan-creation options.  Set struct_size = sizeof(rfx_plan_options); zero in every other field means "default". */
+/* Which plan (layouts + kernels) a parameter set gets */
+typedef enum {
+  RFX_LAYOUT_AUTO = 0,    /* 17640 / 4410 / 441 (the reference's geometry at 44.1 kHz): the specialised engine and its slot-major
+                             frames; every other geometry: the generic plan (plain bin-ordered frames) */
+  RFX_LAYOUT_GENERIC = 1  /* the generic plan also for 17640 / 4410 / 441: a second, independent implementation of the same
+                             transform (row family with h = 441, or the generic FFT engine with RFX_ENGINE_GENERIC) - cross-checks */
+} rfx_plan_layout;
+
+/* Plan-creation options.  Set struct_size = sizeof(rfx_plan_options); zero in every other field means "default".
+ * This struct is the library's ONLY configuration surface: a release build reads no environment variable (the RFX_*
+ * experiment switches of the source exist only in builds made with -DRFX_ABLATION, tools/build_variants.sh). */
 typedef struct {
   uint32_t struct_size;
   int32_t gl_form;             /* rfx_gl_form */
   int32_t gl_frames_per_slot;  /* RFX_GL_FORM_AUTO takes the per-frame form up to this many frames per resident
                                   workgroup slot of the chip (0 = default, 4: the measured crossover, 8 tiles per call) */
   int32_t frame_engine;        /* rfx_frame_engine */
+  int32_t plan_layout;         /* rfx_plan_layout; added in round 4 - a caller built against the shorter struct gets AUTO */
 } rfx_plan_options;
 
 /* rfx_plan_create with options (NULL = defaults = rfx_plan_create). */

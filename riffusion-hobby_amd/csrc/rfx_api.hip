@@ -197,6 +197,17 @@ int rfx_plan_create(const rfx_params* params, const float* h_window, const float
   return rfx_plan_create_ex(params, h_window, h_melfb, device, nullptr, out_plan);
 }
 
+// Experiment switches (RFX_* environment variables) exist only in builds made with -DRFX_ABLATION (tools/build_variants.sh):
+// a release build of librfx.so reads no environment variable at all, rfx_plan_options is its only configuration surface.
+static inline const char* abl_env(const char* name) {
+#ifdef RFX_ABLATION
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const float* h_melfb, int device,
                        const rfx_plan_options* options, rfx_plan** out_plan) {
   if (!params || !out_plan || !h_window) return fail(RFX_ERR_INVALID, "rfx_plan_create: null argument");
@@ -210,9 +221,11 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: gl_form must be RFX_GL_FORM_AUTO / _RUNS / _FRAMES, gl_frames_per_slot >= 0");
     if (opt.frame_engine < RFX_ENGINE_AUTO || opt.frame_engine > RFX_ENGINE_GENERIC)
       return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: frame_engine must be RFX_ENGINE_AUTO or RFX_ENGINE_GENERIC");
+    if (opt.plan_layout < RFX_LAYOUT_AUTO || opt.plan_layout > RFX_LAYOUT_GENERIC)
+      return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: plan_layout must be RFX_LAYOUT_AUTO or RFX_LAYOUT_GENERIC");
   }
   const bool generic = params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop ||
-                       getenv("RFX_FORCE_GENERIC") != nullptr;
+                       opt.plan_layout == RFX_LAYOUT_GENERIC;
   GenGeom gg{};
   if (generic) {
     // any geometry torch.stft accepts (0 < hop, 0 < win <= n_fft) whose FFT length factors into the implemented radices
@@ -238,7 +251,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     // threads per workgroup: measured on MI355X, the engine is latency bound and more waves win over fuller rounds
     // (48 kHz, 64 tiles x 32 iterations: 512 threads 121 ms, 384: 134, 320 - the count gen_pick_threads prefers: 155, 256: 163)
     gg.nthr = 512;
-    if (const char* e = getenv("RFX_GEN_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 512 && v % 64 == 0) gg.nthr = v; }
+    if (const char* e = abl_env("RFX_GEN_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 512 && v % 64 == 0) gg.nthr = v; }
     {  // LDS padding: keep as many workgroups per CU as the unpadded buffer allows
       const size_t tables = sizeof(cf) * (2 * (size_t)kGenTwLo + gg.nhi + gg.nhi2);
       const size_t plain = sizeof(cf) * (size_t)gg.nc + tables + 512;
@@ -247,7 +260,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       if (per_cu > 1024 / gg.nthr) per_cu = 1024 / gg.nthr;
       const size_t room = (160u * 1024u) / per_cu - tables - 512;
       gg.pad_shift = gen_pick_pad(gg, (int)(room / sizeof(cf)));
-      if (const char* e = getenv("RFX_GEN_PAD")) { const int v = atoi(e); if (v == 0 || (v >= 3 && v <= 8)) gg.pad_shift = v; }
+      if (const char* e = abl_env("RFX_GEN_PAD")) { const int v = atoi(e); if (v == 0 || (v >= 3 && v <= 8)) gg.pad_shift = v; }
       if (gen_lds_bytes(gg) > 160u * 1024u) gg.pad_shift = 0;
       if (gen_lds_bytes(gg) > 160u * 1024u)
         return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: n_fft = " + std::to_string(params->n_fft) + ": the frame's FFT buffer and twiddle tables (" +
@@ -258,7 +271,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   // Griffin-Lim of the geometries with n_fft = 40 h, win_length = 10 h (the default 400 / 100 ms at 48 / 32 / 24 / 16 / 8 kHz)
   // runs on the row-family kernels; the generic engine keeps everything else of the plan (layouts, forward path)
   FamGeom fam{};
-  bool fam_ok = generic && opt.frame_engine != RFX_ENGINE_GENERIC && getenv("RFX_NO_FAMILY") == nullptr &&
+  bool fam_ok = generic && opt.frame_engine != RFX_ENGINE_GENERIC &&
                 fam_make_geom(params->n_fft, params->win_length, params->hop_length, &fam);
   if (fam_ok) {
     // pad the rows by up to seven elements (bank spread of the row-to-row accesses) as long as that costs no resident workgroup
@@ -297,15 +310,15 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     RFX_HIP(prepare_fam_kernels(fam));
     pl->fam = fam;
     pl->fam_wgs_per_cu = fam_blocks_per_cu(fam);
-    if (const char* e = getenv("RFX_FAM_WGS_PER_CU")) pl->fam_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = abl_env("RFX_FAM_WGS_PER_CU")) pl->fam_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
   }
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
-  if (const char* e = getenv("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
-  pl->imel_variant = getenv("RFX_IMEL_GENERAL") ? 2 : getenv("RFX_IMEL_UNIFORM") ? 1 : getenv("RFX_IMEL_NO_PAIR") ? 3 : 0;  // 3: best one-frame kernel
+  if (const char* e = abl_env("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
+  pl->imel_variant = abl_env("RFX_IMEL_GENERAL") ? 2 : abl_env("RFX_IMEL_UNIFORM") ? 1 : abl_env("RFX_IMEL_NO_PAIR") ? 3 : 0;  // 3: best one-frame kernel
   // which Griffin-Lim device form a call takes: the options of rfx_plan_create_ex decide; the environment (read here, once)
   // only changes what RFX_GL_FORM_AUTO / the default threshold mean, for experiments
-  if (const char* e = getenv("RFX_GL_LATENCY_MODE")) pl->gl_latency_mode = atoi(e) != 0;
-  if (const char* e = getenv("RFX_GL_LATENCY_FRAMES")) pl->gl_latency_frames_per_slot = atoi(e) > 0 ? atoi(e) : 4;
+  if (const char* e = abl_env("RFX_GL_LATENCY_MODE")) pl->gl_latency_mode = atoi(e) != 0;
+  if (const char* e = abl_env("RFX_GL_LATENCY_FRAMES")) pl->gl_latency_frames_per_slot = atoi(e) > 0 ? atoi(e) : 4;
   pl->gl_form = opt.gl_form;
   if (opt.gl_frames_per_slot > 0) pl->gl_latency_frames_per_slot = opt.gl_frames_per_slot;
 #ifdef RFX_TIMING
@@ -526,12 +539,6 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
         }
       }
     }
-    bool pair_ok = fast && fast_code == 2 && unit_form && M == 512;
-    if (pair_ok) {
-      std::vector<int> cnt2(M, 0);
-      for (int f = f_lo; f < f_hi; ++f) cnt2[bin_m0[f]]++;
-      for (int t2 = 0; t2 < 256 && pair_ok; ++t2) pair_ok = cnt2[M - 1 - t2] >= rfx::kImelHiMin[t2 >> 6];
-    }
     pl->imel_ok = ok;
     pl->imel_why = why;
     // ---- fused forward path: per-filter band tables, weights transposed so that lane m reads row i coalesced
@@ -567,7 +574,9 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->fwd_ok = true;
       // product form of the fused kernel (stft_mel2_kernel).  Needs the group structure of the bank: active bins contiguous,
       // first-filter index non-decreasing, so that filter m = (w1 products of group m-1) + (w0 products of group m).
-      if (!generic && M <= 2 * kThreads && getenv("RFX_FWD_V1") == nullptr) {
+      // Its sum phase gives every thread one filter and the first wave a second one: Mpad <= kThreads + 64 (banks of up to 512
+      // filters); wider banks keep the table form (stft_mel_kernel), which handles two filters per thread up to 2 * kThreads.
+      if (!generic && Mpad <= kThreads + 64 && abl_env("RFX_FWD_V1") == nullptr) {
         bool v2 = true;
         std::vector<int> cnt(M, 0), gfirst(M, 0);
         int prev = 0;
@@ -634,8 +643,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
           }
         }
       }
-      pl->fwd_unfused = getenv("RFX_FWD_UNFUSED") != nullptr;
-      if (const char* e = getenv("RFX_FWD_RUN")) pl->fwd_run_cap = atoi(e) > 0 ? atoi(e) : 64;
+      pl->fwd_unfused = abl_env("RFX_FWD_UNFUSED") != nullptr;
+      if (const char* e = abl_env("RFX_FWD_RUN")) pl->fwd_run_cap = atoi(e) > 0 ? atoi(e) : 64;
     }
     if (ok) {
       // one device blob: csr_w | csr_ptr | band_lo | bin_m0 | bin_w0 | bin_w1 | bin_pos | bin_pos2
@@ -669,7 +678,6 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->imel.grp_start = (const int*)(d + o_gs);
       pl->imel.fast_ok = fast ? fast_code : 0;
       pl->imel.unit_form = fast && unit_form ? 1 : 0;
-      pl->imel.pair_ok = pair_ok ? 1 : 0;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;

@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
   constexpr bool TWL = fam_twiddles_in_lds(RA, RB);
   __shared__ __attribute__((aligned(16))) cf twa_lds[TWL ? RB * (RA - 1) : 1];
   if (TWL)
-    for (int i = tid; i < RB * (RA - 1); i += NT) twa_lds[i] = a.twa[i];  // (the first barrier of the loop precedes its first use)
+    for (int i = tid; i < RB * (RA - 1); i += NT) twa_lds[i] = a.twa[i];
+  __syncthreads();  // the first pass-A read of the frame loop may precede the loop's first barrier, and reads other waves' entries
   FamTwA<RA, TWL> wa;
   wa.src = make_rsrc(a.twa, (size_t)RB * (RA - 1) * sizeof(cf));
   wa.voff = (unsigned)iA * ((RA - 1) * 8u);
@@ -301,6 +302,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
   __shared__ __attribute__((aligned(16))) cf twa_lds[TWL ? RB * (RA - 1) : 1];
   if (TWL)
     for (int i = tid; i < RB * (RA - 1); i += NT) twa_lds[i] = a.twa[i];
+  __syncthreads();  // as in fam_gl_kernel: the table must be complete before the first pass A
   FamTwA<RA, TWL> wa;
   wa.src = make_rsrc(a.twa, (size_t)RB * (RA - 1) * sizeof(cf));
   wa.voff = (unsigned)iA * ((RA - 1) * 8u);

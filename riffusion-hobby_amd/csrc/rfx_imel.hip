@@ -237,6 +237,96 @@ __device__ __forceinline__ float clamp_step(float x) {
 #endif
 }
 
+#ifndef RFX_IMEL_PK
+#define RFX_IMEL_PK 1
+#endif
+#if RFX_IMEL_PK
+// Round 4: the per-bin state lives in register PAIRS (bins 2i and 2i+1 of the group) and every operation of the step is one
+// v_pk_*_f32: the step is bound by the issue slots of the frame's heaviest wave, and a packed instruction does
+// the work of two plain ones in one slot.  The arithmetic per bin is the plain form's, operation for operation: the group
+// sums were already accumulated as even / odd partial sums, now the two halves of one accumulator.  A padding half (odd
+// bin counts) carries w0 = w1 = 0 like every unused slot.
+using c2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c2 bc2(float x) { return c2{x, x}; }
+// spec = clamp(spec + nl * buf, 0, 1): the output clamp of the packed FMA (the compiler does not fold it into v_pk_fma_f32: two
+// v_max per pair); nl = -lr * gradient scale sits in both halves of an SGPR pair
+__device__ __forceinline__ c2 pk_step_clamp(c2 spec, unsigned long long nl2, c2 buf) {
+#if RFX_IMEL_CLAMP
+  asm("v_pk_fma_f32 %0, %1, %2, %0 clamp" : "+v"(spec) : "s"(nl2), "v"(buf));
+  return spec;
+#else
+  const float nl = __builtin_bit_cast(float, (unsigned)nl2);
+  const c2 r = __builtin_elementwise_fma(bc2(nl), buf, spec);
+  return c2{fmaxf(0.f, r.x), fmaxf(0.f, r.y)};
+#endif
+}
+
+template <int N, bool UF>
+struct GroupState {
+  static constexpr int NP = (N + 1) / 2;
+  c2 spec[NP], buf[NP], w0[NP], w1[NP];
+  int f0, n;  // first bin, bin count
+};
+
+template <int N, bool UF>
+__device__ __forceinline__ void group_load(GroupState<N, UF>& g, int grp, const ImelArgs& a, int frame, unsigned rbase, float scale) {
+  const ImelTables& tb = a.tb;
+  g.f0 = grp >= 0 ? tb.grp_start[grp] : 0;
+  g.n = grp >= 0 ? tb.grp_start[grp + 1] - g.f0 : 0;
+#pragma unroll
+  for (int i = 0; i < 2 * g.NP; ++i) {
+    const bool ok = i < g.n;
+    const int f = g.f0 + (ok ? i : 0);
+    const float w0 = ok ? tb.bin_w0[f] : 0.f, w1 = ok ? tb.bin_w1[f] : 0.f;
+    const float sp = ok ? scale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
+    if (i & 1) { g.w0[i >> 1].y = w0; g.w1[i >> 1].y = w1; g.spec[i >> 1].y = sp; g.buf[i >> 1].y = 0.f; }
+    else       { g.w0[i >> 1].x = w0; g.w1[i >> 1].x = w1; g.spec[i >> 1].x = sp; g.buf[i >> 1].x = 0.f; }
+  }
+}
+template <int N, bool UF>
+__device__ __forceinline__ void group_ab(const GroupState<N, UF>& g, float& A, float& B) {
+  c2 sa = bc2(0.f), sb = bc2(0.f);
+#pragma unroll
+  for (int i = 0; i < g.NP; ++i) {
+    sa = __builtin_elementwise_fma(g.w0[i], g.spec[i], sa);
+    sb = __builtin_elementwise_fma(g.w1[i], g.spec[i], sb);
+  }
+  A = sa.x + sa.y;
+  B = sb.x + sb.y;
+}
+template <int N, bool UF>
+__device__ __forceinline__ void group_step(GroupState<N, UF>& g, float d0, float d1, float mom, unsigned long long nl2) {
+  const c2 vm = bc2(mom), v0 = bc2(d0), v1 = bc2(d1), vd = bc2(d0 - d1);
+#pragma unroll
+  for (int i = 0; i < g.NP; ++i) {
+    // torch.optim.SGD: buf.mul_(momentum).add_(grad), in place (see the plain form below)
+    c2 bnew;
+    if (UF) {
+      bnew = __builtin_elementwise_fma(vm, g.buf[i], v1);
+      bnew = __builtin_elementwise_fma(vd, g.w0[i], bnew);
+    } else {
+      bnew = vm * g.buf[i];
+      bnew = __builtin_elementwise_fma(v0, g.w0[i], bnew);
+      bnew = __builtin_elementwise_fma(v1, g.w1[i], bnew);
+    }
+    g.buf[i] = bnew;
+  }
+#pragma unroll
+  for (int i = 0; i < g.NP; ++i) g.spec[i] = pk_step_clamp(g.spec[i], nl2, g.buf[i]);
+}
+template <int N, bool UF>
+__device__ __forceinline__ void group_store(const GroupState<N, UF>& g, const ImelTables& tb, float* out, float unscale) {
+#pragma unroll
+  for (int i = 0; i < 2 * g.NP; ++i)
+    if (i < g.n) {
+      const int f = g.f0 + i;
+      const float v = unscale * ((i & 1) ? g.spec[i >> 1].y : g.spec[i >> 1].x);
+      out[tb.bin_pos[f]] = v;
+      const int p2 = tb.bin_pos2[f];
+      if (p2 >= 0) out[p2] = v;
+    }
+}
+#else
 template <int N, bool UF>
 struct GroupState {
   float spec[N], buf[N], w0[N], w1[N];
@@ -274,7 +364,8 @@ __device__ __forceinline__ void group_ab(const GroupState<N, UF>& g, float& A, f
   B = b0 + b1;
 }
 template <int N, bool UF>
-__device__ __forceinline__ void group_step(GroupState<N, UF>& g, float d0, float d1, float mom, float lrg) {
+__device__ __forceinline__ void group_step(GroupState<N, UF>& g, float d0, float d1, float mom, unsigned long long nl2) {
+  const float lrg = -__builtin_bit_cast(float, (unsigned)nl2);
   const float dd = d0 - d1;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -306,6 +397,8 @@ __device__ __forceinline__ void group_store(const GroupState<N, UF>& g, const Im
       if (p2 >= 0) out[p2] = v;
     }
 }
+
+#endif
 
 // `tid` is the thread's ROLE (0..255: which two groups it owns; roles 64c..64c+63 form size class c), not its hardware
 // index: the kernels below deal the four classes to the waves of a workgroup in different orders.  `frame` is the frame
@@ -341,6 +434,9 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
   // The momentum buffer is kept in units of the gradient scale g = -2/(C T) of the loss mean (buf = g buf''): the step
   // spec -= lr buf becomes spec = fma(-lr g, buf'', spec) and the four products g * residual per step disappear
   const float lrg = a.lr * (-2.0f / (float)(a.C * a.T));
+  // -lr g in both halves of an SGPR pair (wave-uniform: from kernel arguments only)
+  const unsigned nlb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, -lrg));
+  const unsigned long long nl2 = ((unsigned long long)nlb << 32) | nlb;
   // an absent group (n_mels < 512) publishes zeros to the dump entry and reads the pads around it: the loop below has no
   // branches, and the four neighbour reads of a step go out together (one LDS round trip, not four)
   const int xL = (gL >= 0 ? gL : M + 1) + 1, xH = (gH >= 0 ? gH : M + 1) + 1;
@@ -369,8 +465,8 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
     const float sq = wave_sum(fmaf(uL, uL, uH * uH));
     if ((tid & 63) == 0) part[4 * it + wave] = sq;
     // (without the unit form the last filter needs nothing either: it has no successor and its d1 multiplies w1 == 0)
-    group_step(lo, dL0, dL1, a.momentum, lrg);
-    group_step(hi, dH0, dH1, a.momentum, lrg);
+    group_step(lo, dL0, dL1, a.momentum, nl2);
+    group_step(hi, dH0, dH1, a.momentum, nl2);
   };
   float* const A0 = Ab, * const A1 = Ab + (M + 4), * const B0 = Bb, * const B1 = Bb + (M + 4);
   int it = 0;
@@ -454,253 +550,9 @@ imel_group_kernel_perwave(ImelArgs a) {
   }
 }
 
-#ifndef RFX_IMEL_PAIR
-#define RFX_IMEL_PAIR 0
-#endif
-#if RFX_IMEL_PAIR
-// ---------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT, measured and rejected (round 3; built only with -DRFX_IMEL_PAIR=1): 5.39 ms per 64 tiles against 4.75 ms for the
-// one-frame kernel above on the same box, rel-L2 against the oracle 9.2e-8 (the same).  Balanced waves do not pay for going
-// from sixteen to twelve waves per CU: the chip wants wave count more than it wants equal waves.
-//
-// Two frames per workgroup, complementary classes per wave.  With one frame per workgroup the four waves of a frame issue
-// 158 / 129 / 121 / 112 instructions per SGD step and meet at one barrier: the step takes as long as the heaviest wave, the
-// other three idle for up to a third of it, and a CU's SIMDs see 1.8 ready waves where 2.15 would saturate them.
-// Here wave w runs class w of frame A AND class 3 - w of frame B in one instruction stream: 269 / 249 / 249 / 269
-// instructions per double step - every wave within 4 % of the mean - and two independent dependency chains per wave.  The
-// long groups drop their second weight altogether (the unit form's B = sum(spec) - A: three registers per bin, so that both
-// frames' state fits 168 VGPRs = three waves per SIMD, six frames in flight per CU instead of four); a thread's unused
-// slots are pinned to zero after every step (they would otherwise drift and pollute the sum), by compile-time index against
-// the class's shortest group.  Same arithmetic per frame as the one-frame body up to the order of the B sum.
-// The fix-up pass (per-clip step counts) keeps the one-frame kernel.
-template <int N, int NMIN>
-struct HiState {
-  float spec[N], buf[N], w0[N];
-  bool valid[N - NMIN > 0 ? N - NMIN : 1];  // slot NMIN + j holds a bin of this lane's group
-  int f0, n;
-};
-template <int N, int NMIN>
-__device__ __forceinline__ void hi_load(HiState<N, NMIN>& g, int grp, const ImelArgs& a, int frame, unsigned rbase, float scale) {
-  const ImelTables& tb = a.tb;
-  g.f0 = grp >= 0 ? tb.grp_start[grp] : 0;
-  g.n = grp >= 0 ? tb.grp_start[grp + 1] - g.f0 : 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const bool ok = i < g.n;
-    const int f = g.f0 + (ok ? i : 0);
-    g.w0[i] = ok ? tb.bin_w0[f] : 0.f;
-    g.spec[i] = ok ? scale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
-    g.buf[i] = 0.f;
-    if (i >= NMIN) g.valid[i - NMIN] = ok;
-  }
-}
-template <int N, int NMIN>
-__device__ __forceinline__ void hi_ab(const HiState<N, NMIN>& g, float& A, float& B) {
-  float a0 = 0.f, a1 = 0.f, s0 = 0.f, s1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < N; i += 2) {
-    a0 = fmaf(g.w0[i], g.spec[i], a0);
-    s0 += g.spec[i];
-    if (i + 1 < N) {
-      a1 = fmaf(g.w0[i + 1], g.spec[i + 1], a1);
-      s1 += g.spec[i + 1];
-    }
-  }
-  A = a0 + a1;
-  B = (s0 + s1) - A;  // w1 = 1 - w0 (checked at plan creation); the last group's B feeds nothing
-}
-template <int N, int NMIN>
-__device__ __forceinline__ void hi_step(HiState<N, NMIN>& g, float d0, float d1, float mom, float lrg) {
-  const float dd = d0 - d1;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    float bnew = fmaf(mom, g.buf[i], d1);
-    bnew = fmaf(dd, g.w0[i], bnew);
-    g.buf[i] = bnew;
-    const float sp = clamp_step(fmaf(-lrg, bnew, g.spec[i]));
-    g.spec[i] = (i < NMIN || g.valid[i - (i >= NMIN ? NMIN : i)]) ? sp : 0.f;
-  }
-}
-template <int N, int NMIN>
-__device__ __forceinline__ void hi_store(const HiState<N, NMIN>& g, const ImelTables& tb, float* out, float unscale) {
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    if (i < g.n) {
-      const int f = g.f0 + i;
-      const float v = unscale * g.spec[i];
-      out[tb.bin_pos[f]] = v;
-      const int p2 = tb.bin_pos2[f];
-      if (p2 >= 0) out[p2] = v;
-    }
-}
-
-// one frame's share of a thread in the paired kernel: role `tid` (class = tid / 64) of frame `frame`
-template <int NLO, int NHI, int NHMIN>
-struct ImelFrame {
-  GroupState<NLO, false> lo;
-  HiState<NHI, NHMIN> hi;
-  float mL0, mL1, mH0, mH1;
-  float* Ab;    // [2][M + 4]
-  float* Bb;    // [2][M + 4]
-  float* part;  // [max_iter][4]
-  int xL, xH, cls;
-  bool noH1;
-
-  __device__ __forceinline__ void init(const ImelArgs& a, char* smem, int tid, int frame, float scale) {
-    const int M = a.M;
-    Ab = reinterpret_cast<float*>(smem);
-    Bb = Ab + 2 * (M + 4);
-    part = Bb + 2 * (M + 4);
-    const int b = frame / a.T, t = frame - b * a.T;
-    const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
-    const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;
-    const int gL = (tid < M - kImelThreads) ? tid : -1;
-    group_load(lo, gL, a, frame, rbase, scale);
-    hi_load(hi, gH, a, frame, rbase, scale);
-    auto melat = [&](int m) { return (m >= 0 && m < M) ? scale * a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
-    mL0 = gL >= 0 ? melat(gL) : 0.f;
-    mL1 = gL >= 0 ? melat(gL + 1) : 0.f;
-    mH0 = gH >= 0 ? melat(gH) : 0.f;
-    mH1 = gH >= 0 ? melat(gH + 1) : 0.f;
-    xL = (gL >= 0 ? gL : M + 1) + 1;
-    xH = (gH >= 0 ? gH : M + 1) + 1;
-    noH1 = gH == M - 1 || gH < 0;
-    cls = tid >> 6;
-  }
-  float AL, BL, AH, BH;
-  __device__ __forceinline__ void publish(int off) {  // off = 0 / M + 4: this step's half of the double buffers
-    group_ab(lo, AL, BL);
-    hi_ab(hi, AH, BH);
-    Ab[off + xL] = AL;
-    Bb[off + xL] = BL;
-    Ab[off + xH] = AH;
-    Bb[off + xH] = BH;
-  }
-  __device__ __forceinline__ void consume(int off, int it, float mom, float lrg, float unscale, bool lane0) {
-    const float bLm = Bb[off + xL - 1], aLp = Ab[off + xL + 1], bHm = Bb[off + xH - 1], aHp = Ab[off + xH + 1];
-    const float dL0 = mL0 - AL - bLm;
-    const float dL1 = mL1 - aLp - BL;
-    const float dH0 = mH0 - AH - bHm;
-    const float dH1 = noH1 ? 0.f : mH1 - aHp - BH;
-    const float uL = unscale * dL0, uH = unscale * dH0;
-    const float sq = wave_sum(fmaf(uL, uL, uH * uH));
-    if (lane0) part[4 * it + cls] = sq;
-    group_step(lo, dL0, dL1, mom, lrg);
-    hi_step(hi, dH0, dH1, mom, lrg);
-  }
-  __device__ __forceinline__ void finish(const ImelArgs& a, int frame, float unscale) {
-    const ImelTables& tb = a.tb;
-    float* out = a.out_slots + (size_t)frame * a.out_stride;
-    group_store(lo, tb, out, unscale);
-    hi_store(hi, tb, out, unscale);
-  }
-};
-
-// the parts of a frame's output that do not depend on the SGD: untouched bins, padding, the loss history
-__device__ __forceinline__ void imel_frame_epilogue(const ImelArgs& a, const float* part, int frame) {
-  const ImelTables& tb = a.tb;
-  const int tid = threadIdx.x;
-  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
-  float* out = a.out_slots + (size_t)frame * a.out_stride;
-  for (int f = tid; f < a.n_stft; f += kImelThreads) {
-    if (f >= tb.f_lo && f < tb.f_hi) continue;
-    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f);
-    out[tb.bin_pos[f]] = v;
-    const int p2 = tb.bin_pos2[f];
-    if (p2 >= 0) out[p2] = v;
-  }
-  if (a.plain) {
-    for (int p = a.n_stft + tid; p < a.out_stride; p += kImelThreads) out[p] = 0.f;
-  } else {
-    for (int p = tid; p < kFrameStride; p += kImelThreads) {
-      int q, kb;
-      if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
-    }
-  }
-  if (a.loss_hist)
-    for (int i = tid; i < a.max_iter; i += kImelThreads)
-      a.loss_hist[(size_t)frame * a.max_iter + i] = (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]);
-}
-
-template <int LA, int HA, int MA, int LB, int HB, int MB>
-__device__ __forceinline__ void imel_pair_body(const ImelArgs& a, char* smemA, char* smemB, int tidA, int tidB, int frameA, int frameB,
-                                               bool liveA, bool liveB) {
-  constexpr float kScale = kImelScale, kUnscale = kImelUnscale;
-  const int M = a.M;
-  ImelFrame<LA, HA, MA> fa;
-  ImelFrame<LB, HB, MB> fb;
-  fa.init(a, smemA, tidA, frameA, kScale);
-  fb.init(a, smemB, tidB, frameB, kScale);
-  // the two frames' LDS regions are contiguous: zero both (pads and dump entries included)
-  {
-    float* z = reinterpret_cast<float*>(smemA < smemB ? smemA : smemB);
-    const int per = (int)(imel_group_lds_bytes(M, a.max_iter) / sizeof(float));
-    for (int i = threadIdx.x; i < 4 * (M + 4); i += kImelThreads) {
-      z[i] = 0.f;
-      z[per + i] = 0.f;
-    }
-  }
-  const float lrg = a.lr * (-2.0f / (float)(a.C * a.T));
-  const bool lane0 = (threadIdx.x & 63) == 0;
-  const int steps = a.max_iter;
-  __syncthreads();
-  int it = 0;
-  for (; it + 1 < steps; it += 2) {
-    fa.publish(0);
-    fb.publish(0);
-    __syncthreads();
-    fa.consume(0, it, a.momentum, lrg, kUnscale, lane0);
-    fb.consume(0, it, a.momentum, lrg, kUnscale, lane0);
-    fa.publish(M + 4);
-    fb.publish(M + 4);
-    __syncthreads();
-    fa.consume(M + 4, it + 1, a.momentum, lrg, kUnscale, lane0);
-    fb.consume(M + 4, it + 1, a.momentum, lrg, kUnscale, lane0);
-  }
-  if (it < steps) {
-    fa.publish(0);
-    fb.publish(0);
-    __syncthreads();
-    fa.consume(0, it, a.momentum, lrg, kUnscale, lane0);
-    fb.consume(0, it, a.momentum, lrg, kUnscale, lane0);
-  }
-  __syncthreads();
-  if (liveA) fa.finish(a, frameA, kUnscale);
-  if (liveB) fb.finish(a, frameB, kUnscale);
-}
-
-#ifndef RFX_IMEL_PAIR_WPE
-#define RFX_IMEL_PAIR_WPE 3
-#endif
-
-template <int WPE>
-__global__ void __launch_bounds__(kImelThreads) __attribute__((amdgpu_waves_per_eu(WPE))) imel_pair_kernel(ImelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int w4 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int nframes = a.B * a.T;
-  int f0 = 2 * blockIdx.x, f1 = 2 * blockIdx.x + 1;
-  const bool live1 = f1 < nframes;
-  if (!live1) f1 = nframes - 1;
-  char* s0 = smem;
-  char* s1 = smem + imel_group_lds_bytes(a.M, a.max_iter);
-  constexpr const int* L = kImelLoCap;
-  constexpr const int* H = kImelHiCap;
-  constexpr const int* Hm = kImelHiMin;
-  // wave w: class w of the first frame and class 3 - w of the second; waves 2 and 3 run the bodies of waves 1 and 0 with the
-  // frames swapped (two instantiations instead of four)
-  switch (w4) {
-    case 0: imel_pair_body<L[0], H[0], Hm[0], L[3], H[3], Hm[3]>(a, s0, s1, 0 * 64 + lane, 3 * 64 + lane, f0, f1, true, live1); break;
-    case 1: imel_pair_body<L[1], H[1], Hm[1], L[2], H[2], Hm[2]>(a, s0, s1, 1 * 64 + lane, 2 * 64 + lane, f0, f1, true, live1); break;
-    case 2: imel_pair_body<L[1], H[1], Hm[1], L[2], H[2], Hm[2]>(a, s1, s0, 1 * 64 + lane, 2 * 64 + lane, f1, f0, live1, true); break;
-    default: imel_pair_body<L[0], H[0], Hm[0], L[3], H[3], Hm[3]>(a, s1, s0, 0 * 64 + lane, 3 * 64 + lane, f1, f0, live1, true); break;
-  }
-  __syncthreads();
-  imel_frame_epilogue(a, reinterpret_cast<const float*>(s0) + 4 * (a.M + 4), f0);
-  if (live1) imel_frame_epilogue(a, reinterpret_cast<const float*>(s1) + 4 * (a.M + 4), f1);
-}
-
-#endif  // RFX_IMEL_PAIR
+// (Round 3 also measured a two-frames-per-workgroup kernel with complementary size classes per wave - every wave within 4 % of
+// the mean instruction count, twelve balanced waves per CU instead of sixteen unbalanced ones: 5.39 ms against 4.75 ms for the
+// kernel above on the same box, profiles/r03b_imel_pair_kernel_experiment.txt.  The code was removed in round 4.)
 
 // one workgroup per clip: replays the reference's stopping rule on the clip-mean loss.  Thread (g, i) sums
 // iteration i over every fourth frame (loads coalesce across i), the four partial sums meet in LDS, then one
@@ -762,13 +614,6 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
     // the fix-up pass runs a different number of steps (and barriers) per clip: one frame per workgroup there
     const bool fixup = a.it_limit != nullptr;
     if (a.tb.fast_ok == 2 && variant != 1) {
-#if RFX_IMEL_PAIR
-      if (a.tb.unit_form && a.tb.pair_ok && RFX_IMEL_UFORM && !fixup && variant != 3) {
-        const int nframes = a.B * a.T;
-        const size_t lds = 2 * imel_group_lds_bytes(a.M, a.max_iter);
-        hipLaunchKernelGGL(imel_pair_kernel<RFX_IMEL_PAIR_WPE>, dim3((nframes + 1) / 2), dim3(kImelThreads), lds, stream, a);
-      } else
-#endif
       if (a.tb.unit_form && RFX_IMEL_UFORM) {
         if (fixup) launch_perwave<1, 0, true>(a, stream); else launch_perwave<RFX_IMEL_FPW, 0, true>(a, stream);
       } else {

@@ -113,9 +113,6 @@ hipError_t launch_mel_gemm(const MelArgs& a, hipStream_t stream);
 // does not fit.
 constexpr int kImelLoCap[4] = {2, 3, 5, 6};
 constexpr int kImelHiCap[4] = {23, 16, 12, 9};
-// shortest long group of each class of the default bank: the two-frames-per-workgroup kernel (imel_pair_kernel) pins the
-// register slots past a group's end to zero, by compile-time index from here on
-constexpr int kImelHiMin[4] = {16, 11, 8, 6};
 // a second set for banks whose edges sit elsewhere: mel_scale_type "slaney" (spectrogram_params.py:35; linear below 1 kHz,
 // so its low groups are longer, and its top groups reach 26 bins)
 constexpr int kImelLoCapWide[4] = {5, 3, 5, 6};
@@ -136,8 +133,6 @@ struct ImelTables {
   int nnz;
   int fast_ok;           // 0: general kernel; 1: group formulation with <8, 24> bins per thread; 2: per-wave budgets (default set) fit too;
                          // 3: only the wide per-wave set fits
-  int pair_ok;           // 1: M == 512 and every long group at least as long as its class's kImelHiMin (rfx_imel.hip): the
-                         // two-frames-per-workgroup kernel may run
   int unit_form;         // 1: in every long group (the top 256) a bin's two weights sum to one (to 1e-6) - the last group, whose second
                          // filter does not exist, carries w1 == 0: the per-wave kernels compute the gradient as d1 + (d0 - d1) w0
 };

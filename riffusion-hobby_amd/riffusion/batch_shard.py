@@ -14,9 +14,10 @@ caller's choice (`gather=`):
 Both collectives move the shards into ONE preallocated tensor (no list of parts + cat).  Backend
 "nccl" is RCCL on ROCm; the CPU tests run the same code over "gloo".
 
-`ChunkSink` is the other half of a scalable batch call: a rank's shard is produced chunk by chunk
-(bounded working set), and each finished chunk is copied to a pinned host buffer on a side stream
-while the next chunk computes, so the device-to-host copy is off the critical path.
+`ChunkSource` / `ChunkSink` are the other half of a scalable batch call: host tiles are staged through pinned memory and
+uploaded on a side stream, chunk k+1 while chunk k computes (the reference's API is host images in, host audio out:
+spectrogram_image_converter.py:65-91); a rank's shard is produced chunk by chunk (bounded working set), and each finished
+chunk is copied to a pinned host buffer on a side stream while the next chunk computes: both copies are off the critical path.
 """
 import typing as T
 
@@ -24,6 +25,12 @@ import torch
 import torch.distributed as dist
 
 GATHER_MODES = ("all", "rank0", "none")
+
+
+def default_gather(group: T.Any) -> str:
+    """`gather=None` at the entry points: with a process group the mode that scales ("none": every rank returns its own
+    clips, no data-path collective); without one the question does not arise."""
+    return "none"
 
 
 def shard_range(n_items: int, world_size: int, rank: int) -> T.Tuple[int, int]:
@@ -80,7 +87,7 @@ def gather_clips(
 
 
 def sharded_map(
-    convert: T.Callable[[int, int], torch.Tensor], n_items: int, group: T.Any = None, gather: str = "all"
+    convert: T.Callable[[int, int], torch.Tensor], n_items: int, group: T.Any = None, gather: str = "none"
 ) -> torch.Tensor:
     """
     The multi-GPU form of a batch call: rank r runs `convert(lo, hi)` on its slice [lo, hi) of the
@@ -103,7 +110,7 @@ def sharded_map(
     return local if full is None else full
 
 
-def result_rows(n_items: int, group: T.Any = None, gather: str = "all") -> T.Tuple[int, int]:
+def result_rows(n_items: int, group: T.Any = None, gather: str = "none") -> T.Tuple[int, int]:
     """Which clips [lo, hi) of the batch a `sharded_map(..., group, gather)` call returns ON THIS RANK."""
     if group is None:
         return 0, n_items
@@ -171,3 +178,57 @@ class ChunkSink:
         if self.side is not None:
             self.side.synchronize()
         return self.out
+
+
+class ChunkSource:
+    """
+    Input side of a shard that is consumed chunk by chunk: `get(i)` returns chunk i = rows [bounds[i][0], bounds[i][1]) of
+    `items` as a tensor on `device`.
+
+    Device input: a view (nothing to move).  Host input, one chunk (one tile per request): one plain upload on the compute
+    stream.  Host input, several chunks: chunk i+1 is copied into one of two pinned staging blocks and uploaded on a SIDE
+    stream while chunk i computes - `get(i)` queues that before it returns chunk i, so by the time the caller has launched
+    chunk i's kernels the next upload is already in flight; the compute stream waits for a chunk's upload event, never the
+    host.  Only chunk 0's upload is exposed (it has nothing to hide behind).
+    """
+
+    def __init__(self, items: torch.Tensor, bounds: T.Sequence[T.Tuple[int, int]], device: torch.device):
+        self.items, self.bounds, self.device = items, list(bounds), torch.device(device)
+        self.staged = items.device.type == "cpu" and self.device.type == "cuda" and len(self.bounds) > 1
+        self.ready: T.Dict[int, T.Tuple[torch.Tensor, T.Any]] = {}
+        if self.staged:
+            self.side = torch.cuda.Stream(self.device)
+            rows = max(b - a for a, b in self.bounds)
+            self.pinned = None if items.is_pinned() else [torch.empty((rows,) + tuple(items.shape[1:]), dtype=items.dtype, pin_memory=True) for _ in range(2)]
+            self.pin_free: T.List[T.Any] = [None, None]  # event after which a staging block may be overwritten
+            self._upload(0)
+
+    def _upload(self, i: int) -> None:
+        a, b = self.bounds[i]
+        if self.pinned is None:
+            src = self.items[a:b]
+        else:
+            j = i & 1
+            if self.pin_free[j] is not None:
+                self.pin_free[j].synchronize()  # the upload that last read this block (two chunks ago) has long finished
+            src = self.pinned[j][: b - a]
+            src.copy_(self.items[a:b])  # pageable -> pinned on the host, while the GPU computes the previous chunk
+        with torch.cuda.stream(self.side):
+            dev = src.to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        if self.pinned is not None:
+            self.pin_free[i & 1] = done
+        self.ready[i] = (dev, done)
+
+    def get(self, i: int) -> torch.Tensor:
+        a, b = self.bounds[i]
+        if not self.staged:
+            return self.items[a:b].to(self.device)
+        dev, done = self.ready.pop(i)
+        if i + 1 < len(self.bounds):
+            self._upload(i + 1)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        dev.record_stream(cur)  # allocated on the side stream, consumed on the compute stream
+        return dev

@@ -102,8 +102,9 @@ class SpectrogramImageConverter:
         return_waveform: bool = False,
         group: T.Any = None,
         tiles_per_call: int = 64,
-        gather: str = "all",
+        gather: T.Optional[str] = None,
         return_device: bool = False,
+        validate: T.Optional[bool] = None,
     ) -> T.Union[np.ndarray, torch.Tensor]:
         """
         (N, H, W, 3) RGB tiles -> (n, samples, C) int16 PCM (or, with `return_waveform`, the (n, C, samples)
@@ -111,16 +112,23 @@ class SpectrogramImageConverter:
 
         `images_u8` is a uint8 array / tensor on any device, or the diffusion pipeline's float [0, 1]
         NHWC tensor (quantised here like `numpy_to_pil`, see `quantize_pipeline_images`; a float input
-        with values above 1 is refused - pass pixel values as uint8).
+        with values outside [0, 1] - or NaN - is refused: pass pixel values as uint8).  `validate` says when
+        that range check runs: None (default) at once for a host tensor, and for a device tensor as a flag
+        computed on the device and read where the call synchronises anyway (the copy of the result to the
+        host) - no host sync on the one-tile-per-request path; True: at once, with a host sync; False: never
+        (`return_device=True` with a device input never synchronises, so None checks nothing there).
+        Host tiles are uploaded chunk by chunk through pinned memory on a side stream (`batch_shard.ChunkSource`).
 
         `group`: a `torch.distributed` process group (or True for the default group).  Every rank
         passes the SAME full batch; rank r converts clips `shard_range(N, world, r)` on its own GPU
         (a clip's channels never leave their rank: they share the SGD loss mean and the peak
         normalisation), `tiles_per_call` clips at a time.  `gather` says which clips a rank RETURNS
         (`batch_shard.result_rows`):
-            "all"   (default) the whole batch on every rank - one RCCL all_gather_into_tensor of the int16 PCM;
+            "none"  (default, also `None`) the own shard only, no collective at all: each rank writes / serves its own
+                    clips, as the reference's consumers do (server.py:159-183, cli.py:172-204) - the mode that scales;
             "rank0" the whole batch on the group's rank 0 (one RCCL gather), the own shard elsewhere;
-            "none"  the own shard only, no collective at all (each rank writes / serves its own clips).
+            "all"   the whole batch on every rank - one RCCL all_gather_into_tensor of the int16 PCM (round 2-3 default:
+                    every rank receives and copies all N clips, so it does not scale; ask for it explicitly).
         Host results are staged through pinned memory; without a collective each chunk's device-to-host
         copy runs on a side stream while the next chunk computes (`batch_shard.ChunkSink`).
         Like the reference, the two random initialisations are not reproducible across different
@@ -130,15 +138,24 @@ class SpectrogramImageConverter:
 
         if tiles_per_call < 1:
             raise ValueError(f"tiles_per_call must be >= 1, got {tiles_per_call}")
+        if gather is None:
+            gather = batch_shard.default_gather(group)
         if gather not in batch_shard.GATHER_MODES:
             raise ValueError(f"gather must be one of {batch_shard.GATHER_MODES}, got {gather!r}")
         conv = self.converter
         plan = conv._plan()
         imgs = torch.as_tensor(np.ascontiguousarray(images_u8) if isinstance(images_u8, np.ndarray) else images_u8)
+        range_msg = ("float images must be the pipeline's [0, 1] output (riffusion_pipeline.py:427-431); "
+                     "pass 0..255 pixel values as uint8")
+        range_ok = None  # device flag of a deferred range check
         if imgs.is_floating_point():
-            if imgs.numel() and float(imgs.max()) > 1.0 + 1e-6:
-                raise ValueError("float images must be the pipeline's [0, 1] output (riffusion_pipeline.py:427-431); "
-                                 "pass 0..255 pixel values as uint8")
+            if imgs.numel() and validate is not False:
+                ok = ((imgs >= 0) & (imgs <= 1.0 + 1e-6)).all()  # NaN compares false
+                if validate or not imgs.is_cuda:
+                    if not bool(ok):
+                        raise ValueError(range_msg)
+                else:
+                    range_ok = ok
             imgs = self.quantize_pipeline_images(imgs)
         n_total = imgs.shape[0]
         C = 2 if self.p.stereo else 1
@@ -154,9 +171,10 @@ class SpectrogramImageConverter:
 
         def convert(lo: int, hi: int) -> torch.Tensor:
             sink = batch_shard.ChunkSink(hi - lo, row_shape, dtype, plan.device, to_host=not (collective or return_device))
-            for a in range(lo, hi, tiles_per_call):  # bounded working set: |S| alone is 19 MB per tile-channel
-                b = min(hi, a + tiles_per_call)
-                mel = plan.image_decode(imgs[a:b].to(plan.device), self.p.stereo, lut)
+            bounds = [(a, min(hi, a + tiles_per_call)) for a in range(lo, hi, tiles_per_call)]  # bounded working set: |S| alone is 19 MB per tile-channel
+            source = batch_shard.ChunkSource(imgs, bounds, plan.device)
+            for i, (a, b) in enumerate(bounds):
+                mel = plan.image_decode(source.get(i), self.p.stereo, lut)
                 wave = conv.waveform_from_mel_amplitudes(mel, seed=base_seed + 2 * a, channels_per_clip=C)
                 if return_waveform:
                     sink.put(a - lo, b - lo, wave.reshape(b - a, C, -1))
@@ -166,9 +184,13 @@ class SpectrogramImageConverter:
             return sink.finish()  # a rank with an empty shard still joins the collective with 0 rows
 
         result = batch_shard.sharded_map(convert, n_total, group, gather)
-        if return_device or not result.is_cuda:
-            return result if return_device else result.numpy()
-        host = torch.empty(result.shape, dtype=result.dtype, pin_memory=True)  # gathered batch: one pinned copy
-        host.copy_(result, non_blocking=True)
-        torch.cuda.current_stream(plan.device).synchronize()
-        return host.numpy()
+        if return_device:
+            return result
+        if result.is_cuda:
+            host = torch.empty(result.shape, dtype=result.dtype, pin_memory=True)  # gathered batch: one pinned copy
+            host.copy_(result, non_blocking=True)
+            torch.cuda.current_stream(plan.device).synchronize()
+            result = host
+        if range_ok is not None and not bool(range_ok):  # the stream has been synchronised above / by the sink: no extra wait
+            raise ValueError(range_msg)
+        return result.numpy()

@@ -92,6 +92,20 @@ void emu_slot_maps(int* bin, int* conj, int* pos_c, int* pos_f) {
       }
 }
 
+// the counter RNG of the random starts (rfx_core.h): `n` values of frame `frame` under `seed`
+void emu_rand_unit(unsigned long long seed, unsigned long long frame, int n, float* out) {
+  const unsigned key = rand_frame_key(seed, frame);
+  for (int f = 0; f < n; ++f) out[f] = rand_unit(key, f);
+}
+void emu_rand_unit_pair(unsigned long long seed, unsigned long long frame, int n, float* out_re_im) {
+  const unsigned key = rand_frame_key(seed, frame);
+  for (int b = 0; b < n; ++b) {
+    const cf r = rand_unit_pair(key, b);
+    out_re_im[2 * b] = r.re;
+    out_re_im[2 * b + 1] = r.im;
+  }
+}
+
 void emu_dft21(float* x, int inv) {
   cf v[21];
   for (int i = 0; i < 21; ++i) v[i] = cf{x[2 * i], x[2 * i + 1]};

@@ -58,16 +58,18 @@ def _map_worker(rank, world, port, n_items):
         calls.append((lo, hi))
         return torch.arange(lo, hi, dtype=torch.int16).reshape(-1, 1, 1).repeat(1, 4, 1)
 
-    full = sharded_map(convert, n_items, dist.group.WORLD)
+    full = sharded_map(convert, n_items, dist.group.WORLD, gather="all")
     assert calls == [shard_range(n_items, world, rank)]  # each rank converts only its own slice, once
     calls.clear()
     assert full.shape == (n_items, 4, 1) and torch.equal(full[:, 0, 0], torch.arange(n_items, dtype=torch.int16))
-    assert torch.equal(sharded_map(convert, n_items, True), full)  # True = default group
-    # gather="none": the own shard only, no collective; gather="rank0": the whole batch on rank 0, own shard elsewhere
+    assert torch.equal(sharded_map(convert, n_items, True, gather="all"), full)  # True = default group
+    # gather="none" (the default since round 4: the mode that scales): the own shard only, no collective;
+    # gather="rank0": the whole batch on rank 0, own shard elsewhere
     lo, hi = shard_range(n_items, world, rank)
-    own = sharded_map(convert, n_items, dist.group.WORLD, gather="none")
+    own = sharded_map(convert, n_items, dist.group.WORLD)
     assert own.shape == (hi - lo, 4, 1) and torch.equal(own[:, 0, 0], torch.arange(lo, hi, dtype=torch.int16))
-    assert result_rows(n_items, dist.group.WORLD, "none") == (lo, hi)
+    assert torch.equal(own, sharded_map(convert, n_items, dist.group.WORLD, gather="none"))
+    assert result_rows(n_items, dist.group.WORLD, "none") == (lo, hi) == result_rows(n_items, dist.group.WORLD)
     r0 = sharded_map(convert, n_items, dist.group.WORLD, gather="rank0")
     assert torch.equal(r0, full if rank == 0 else own)
     assert result_rows(n_items, dist.group.WORLD, "rank0") == ((0, n_items) if rank == 0 else (lo, hi))

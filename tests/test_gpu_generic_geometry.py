@@ -146,14 +146,14 @@ def test_images_round_trip_at_48k():
     assert SpectrogramParams.from_exif(image.getexif()).sample_rate == 48000
 
 
-def test_generic_engine_agrees_with_specialised_engine_at_44k(O, monkeypatch):
-    """RFX_FORCE_GENERIC (read at plan creation) puts the default geometry on the generic engine: two independent
-    implementations of the same transform must agree far below the oracle tolerances."""
+def test_generic_engine_agrees_with_specialised_engine_at_44k(O):
+    """rfx_plan_options.plan_layout = RFX_LAYOUT_GENERIC with frame_engine = RFX_ENGINE_GENERIC puts the default geometry on
+    the generic FFT engine: two independent implementations of the same transform must agree far below the oracle tolerances."""
+    from riffusion import _hip
+
     fast = _plan(_params())
-    monkeypatch.setenv("RFX_FORCE_GENERIC", "1")
-    slow = _plan_generic_only(_params(max_mel_iters=199))  # a different cache key -> a fresh plan, created under the override
-    monkeypatch.delenv("RFX_FORCE_GENERIC")
-    assert slow.generic and not fast.generic
+    slow = _hip.get_plan(_params(), "cuda", frame_engine="generic", plan_layout="generic")
+    assert slow.generic and not fast.generic and slow.griffinlim_engine == "generic"
     wave = synthetic_wave(2, 441 * 50, seed=1).cuda()
     _, sf, T = fast.stft(wave, want_mag=False, want_spec=True)
     _, ss, _ = slow.stft(wave, want_mag=False, want_spec=True)
@@ -240,14 +240,14 @@ def test_row_family_hop_is_free_and_other_windows_stay_generic(O):
     assert _plan(_params()).griffinlim_engine == "specialised"
 
 
-def test_row_family_at_44k_agrees_with_specialised_engine(O, monkeypatch):
-    """RFX_FORCE_GENERIC puts the default geometry on the generic plan, whose Griffin-Lim then takes the row family with
-    h = 441 = 21 x 21: the specialised engine's own factorisation written a second time."""
+def test_row_family_at_44k_agrees_with_specialised_engine(O):
+    """rfx_plan_options.plan_layout = RFX_LAYOUT_GENERIC puts the default geometry on the generic plan, whose Griffin-Lim then
+    takes the row family with h = 441 = 21 x 21: the specialised engine's own factorisation written a second time."""
+    from riffusion import _hip
+
     fast = _plan(_params())
-    monkeypatch.setenv("RFX_FORCE_GENERIC", "1")
-    fam = _plan(_params(max_mel_iters=198))  # a different cache key -> a fresh plan, created under the override
-    monkeypatch.delenv("RFX_FORCE_GENERIC")
-    assert fam.griffinlim_engine == "row-family" and fast.griffinlim_engine == "specialised"
+    fam = _hip.get_plan(_params(), "cuda", plan_layout="generic")
+    assert fam.generic and fam.griffinlim_engine == "row-family" and fast.griffinlim_engine == "specialised"
     T = 50
     g = torch.Generator().manual_seed(0)
     mag = torch.rand(2, 8821, T, generator=g) * 1000

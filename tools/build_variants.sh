@@ -7,7 +7,7 @@ SRC=${SRC:-$ROOT/riffusion-hobby_amd/csrc}
 mkdir -p $ROOT/build_var
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}; [ "$flags" = "$spec" ] && flags=""
-  ( cd $SRC && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-result -fno-slp-vectorize \
+  ( cd $SRC && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-result -fno-slp-vectorize -DRFX_ABLATION \
       -I $ROOT/include $flags *.hip -o $ROOT/build_var/librfx_$name.so ) &
 done
 wait
