@@ -1118,6 +1118,30 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     const int T = stft_frames(plan, Lw);
     float* mag = (float*)d_workspace;
     float* mel_tm = (float*)((char*)d_workspace + align_up((size_t)B * T * plan->gg.fs * sizeof(float), 256));
+    if (plan->fam_ok && !plan->fwd_unfused) {  // row family: transform and banded projection in one kernel, |X| stays on chip
+      const FamGeom& f = plan->fam;
+      FamFwdArgs fa{};
+      fa.g = f;
+      fa.wave = d_wave;
+      fa.wave_stride = (size_t)Lw;
+      fa.Lw = Lw;
+      fa.fs_plain = plan->gg.fs;
+      fa.tw1 = plan->d_fam_tw;
+      fa.twa = plan->d_fam_tw + (size_t)kFamRows * f.h;
+      fa.win = plan->d_win;
+      fa.B = B;
+      fa.T = T;
+      fa.mel_tm = mel_tm;
+      fa.band_wt = plan->d_band_wt;
+      fa.band_lo = plan->d_band_lo;
+      fa.band_len = plan->d_band_lo + plan->Mpad;
+      fa.M = plan->p.n_mels;
+      fa.Mpad = plan->Mpad;
+      const long long nframes = (long long)B * T, slots = (long long)plan->num_cus * plan->fam_wgs_per_cu;
+      RFX_HIP(launch_fam_fwd(2, fa, (int)(nframes < slots ? nframes : slots), (hipStream_t)stream));
+      RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+      return RFX_OK;
+    }
     int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
     if (rc) return rc;
     RFX_HIP(launch_gen_mel(mag, mel_tm, plan->d_band_wt, plan->d_band_lo, plan->d_band_lo + plan->Mpad, (long long)B * T, plan->gg.fs,

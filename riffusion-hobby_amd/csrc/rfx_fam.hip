@@ -346,10 +346,16 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
     RFX_SCHED_FENCE();
     __syncthreads();  // every row has been read: the memory is now the bin-ordered frame
     if (actB) {
+      // slot s of this thread holds k = k0 + 40 RA s.  k0 is frame-invariant, and the compiler would hoist all RB bin positions
+      // and conjugate flags out of the frame loop - into scratch at the 128-register bound (68 spilled registers in round 3):
+      // the empty asm makes k0 opaque per frame, two integer instructions per slot instead
+      int k0 = rowB + 40 * pB;
+      asm volatile("" : "+v"(k0));
 #pragma unroll
       for (int s = 0; s < RB; ++s) {
-        bool cj;
-        const int bin = fam_slot_bin(a.g, rowB, pB, s, &cj);
+        const int k = k0 + 40 * RA * s;
+        const bool cj = k > a.g.n_fft / 2;
+        const int bin = cj ? a.g.n_fft - k : k;
         if (fam_slot_is_primary(rowB, cj)) {  // rows 0 and 20 hold their bins twice: the direct slot writes
           if (MODE == 1) cube[bin] = cf{R[s].re, cj ? -R[s].im : R[s].im};
           // v_sqrt_f32 (1 ulp) instead of the IEEE expansion: |X| carries ~1e-7 relative error from the transform anyway
@@ -360,7 +366,30 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
     RFX_SCHED_FENCE();
     __syncthreads();
     if (gf + gridDim.x < nframes) load_frame_inputs(gf + gridDim.x);  // in flight underneath the output loop
-    if (MODE == 1) {
+    if (MODE == 2) {
+      // banded mel projection straight from the frame in LDS (the reference multiplies the dense filterbank,
+      // spectrogram_converter.py:76-84, :185): a filter's weights come eight at a time from the L2-resident table, summed in
+      // increasing bin order like gen_mel_kernel
+      for (int m = tid; m < a.Mpad; m += NT) {
+        float acc = 0.f;
+        if (m < a.M) {
+          const int lo = a.band_lo[m], n = a.band_len[m];
+          const float* __restrict__ wcol = a.band_wt + m;
+          for (int i = 0; i < n; i += 8) {
+            float w[8], v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              w[e] = wcol[(size_t)(i + e) * a.Mpad];
+              const int q = lo + i + e;
+              v[e] = magl[q < n_stft ? q : n_stft - 1];  // (rows past the filter's end carry zero weights)
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(w[e], v[e], acc);
+          }
+        }
+        a.mel_tm[(size_t)gf * a.Mpad + m] = acc;
+      }
+    } else if (MODE == 1) {
       cf* __restrict__ out = a.spec + (size_t)gf * fs;
       for (int k = tid; k < fs; k += NT) out[k] = k < n_stft ? cube[k] : cf{0.f, 0.f};
     } else {
@@ -409,7 +438,7 @@ static FamGlFn fam_fn(const FamGeom& g, int mode) {
 using FamFwdFn = void (*)(FamFwdArgs);
 template <int RA, int RB>
 static FamFwdFn fam_fwd_fn(int mode) {
-  return mode == 0 ? fam_fwd_kernel<0, RA, RB> : fam_fwd_kernel<1, RA, RB>;
+  return mode == 0 ? fam_fwd_kernel<0, RA, RB> : mode == 1 ? fam_fwd_kernel<1, RA, RB> : fam_fwd_kernel<2, RA, RB>;
 }
 static FamFwdFn fam_fwd_fn(const FamGeom& g, int mode) {
   switch (g.h) {
@@ -429,7 +458,7 @@ hipError_t launch_fam_fwd(int mode, const FamFwdArgs& a, int nblocks, hipStream_
 }
 
 hipError_t prepare_fam_kernels(const FamGeom& g) {
-  for (int mode = 0; mode < 2; ++mode) {
+  for (int mode = 0; mode < 3; ++mode) {
     const hipError_t e = hipFuncSetAttribute((const void*)fam_fwd_fn(g, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam_lds_bytes(g));
     if (e != hipSuccess) return e;
   }

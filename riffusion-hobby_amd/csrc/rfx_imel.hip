@@ -461,9 +461,11 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
     const float dH0 = mH0 - AH - bHm;
     const float dH1 = noH1 ? 0.f : mH1 - aHp - BH;
     // every filter's residual is owned exactly once; the loss history is kept in the reference's units
+#ifndef RFX_ABL_IMEL_NO_LOSS  // (ablation: what the per-step loss history costs)
     const float uL = kUnscale * dL0, uH = kUnscale * dH0;
     const float sq = wave_sum(fmaf(uL, uL, uH * uH));
     if ((tid & 63) == 0) part[4 * it + wave] = sq;
+#endif
     // (without the unit form the last filter needs nothing either: it has no successor and its d1 multiplies w1 == 0)
     group_step(lo, dL0, dL1, a.momentum, nl2);
     group_step(hi, dH0, dH1, a.momentum, nl2);

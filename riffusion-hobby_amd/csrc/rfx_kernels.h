@@ -219,7 +219,8 @@ struct FamGlArgs {
   unsigned long long seed;
   int B, T, L;
 };
-// forward STFT of the family geometries into the plan's plain layout (mode 0: |X| floats, mode 1: X complex)
+// forward STFT of the family geometries into the plan's plain layout (mode 0: |X| floats, mode 1: X complex), or (mode 2) fused
+// with the banded mel projection: |X| never leaves the chip, the frame-major mel amplitudes do (spectrogram_converter.py:165-185)
 struct FamFwdArgs {
   FamGeom g;
   const float* wave;     // [B][wave_stride], Lw valid samples each
@@ -232,6 +233,12 @@ struct FamFwdArgs {
   const cf* twa;
   const float* win;
   int B, T;
+  // mode 2: the band tables of gen_mel_kernel (weights transposed [rows][Mpad], rows a multiple of eight, zero past a filter's end)
+  float* mel_tm;         // [B*T][Mpad] frame-major mel amplitudes (mel_transpose_kernel turns them into (B, M, T))
+  const float* band_wt;
+  const int* band_lo;
+  const int* band_len;
+  int M, Mpad;
 };
 hipError_t launch_fam_fwd(int mode, const FamFwdArgs& a, int nblocks, hipStream_t stream);
 hipError_t prepare_fam_kernels(const FamGeom& g);

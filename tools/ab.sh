@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for v in "$@"; do
   export RFX_LIB_PATH=$GRAFT_REPO_ROOT/build_var/librfx_$v.so
   echo "=== $v"
-  python tools/probe_gl.py 2>&1 | grep -v amdgpu.ids | tail -2
+  python tools/probe_gl.py 2>&1 | grep -v amdgpu.ids | tail -${TAIL:-2}
   [ -n "$FWD" ] && python bench.py --workload forward --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('forward', d['value'], d['unit'], d.get('stages'))"
   [ -n "$RATES" ] && TAG=$v python tools/probe_fam.py 2>&1 | grep -v amdgpu.ids | tail -1
 done | tee gpurun_out/ab.log

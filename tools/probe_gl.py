@@ -10,7 +10,7 @@ B = int(os.environ.get("B", 64)); T = 512; n_iter = int(os.environ.get("ITERS", 
 plan = _hip.get_plan(SpectrogramParams(), "cuda")
 S = torch.rand(B * T, plan.frame_stride, device="cuda") * 1e6
 ws = torch.empty(plan.lib.rfx_griffinlim_workspace_bytes(plan.handle, B, T), dtype=torch.uint8, device="cuda")
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", 3))):
     torch.cuda.synchronize(); t = time.time()
     out = plan.griffinlim(S, B, T, n_iter, 0.99, seed=rep, workspace=ws)
     torch.cuda.synchronize(); dt = time.time() - t
