@@ -387,13 +387,13 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   }
   if (fam_ok) {
     const FamGeom& f = pl->fam;
-    std::vector<cf> tw((size_t)kFamRows * f.h + (size_t)f.rb * (f.ra - 1));
-    for (int k1 = 0; k1 < kFamRows; ++k1)
-      for (int n = 0; n < f.h; ++n) {
-        const long long e = ((long long)k1 * (n + 15 * f.h)) % f.n_fft;
+    std::vector<cf> tw((size_t)f.rows * f.h + (size_t)f.rb * (f.ra - 1));
+    for (int k1 = 0; k1 < f.rows; ++k1)
+      for (int n = 0; n < f.h; ++n) {  // g(n)^k1 = exp(-2 pi i k1 (n + left) / n_fft); left = 15 h in the 40 h family
+        const long long e = ((long long)k1 * (n + f.left)) % f.n_fft;
         tw[(size_t)k1 * f.h + n] = cf{(float)cos(PI2 * (double)e / f.n_fft), (float)(-sin(PI2 * (double)e / f.n_fft))};
       }
-    cf* twa = tw.data() + (size_t)kFamRows * f.h;
+    cf* twa = tw.data() + (size_t)f.rows * f.h;
     for (int i = 0; i < f.rb; ++i)
       for (int q = 1; q < f.ra; ++q) {
         const int e = (i * q) % f.h;
@@ -402,7 +402,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     RFX_HIP(hipMalloc(&pl->d_fam_tw, tw.size() * sizeof(cf)));
     RFX_HIP(hipMemcpy(pl->d_fam_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
     std::vector<int> binof((size_t)f.fsf, -1);
-    for (int k1 = 0; k1 < kFamRows; ++k1)
+    for (int k1 = 0; k1 < f.rows; ++k1)
       for (int q = 0; q < f.ra; ++q)
         for (int s2 = 0; s2 < f.rb; ++s2) binof[(size_t)s2 * f.nthr + k1 * f.ra + q] = fam_slot_bin(f, k1, q, s2, nullptr);
     RFX_HIP(hipMalloc(&pl->d_fam_binof, binof.size() * sizeof(int)));
@@ -754,7 +754,7 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
     fa.spec = (cf*)d_spec_slots;
     fa.fs_plain = plan->gg.fs;
     fa.tw1 = plan->d_fam_tw;
-    fa.twa = plan->d_fam_tw + (size_t)kFamRows * f.h;
+    fa.twa = plan->d_fam_tw + (size_t)f.rows * f.h;
     fa.win = plan->d_win;
     fa.B = B;
     fa.T = stft_frames(plan, Lw);
@@ -880,7 +880,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     fa.audio_stride = (size_t)Lpad;
     fa.frames = frames;
     fa.tw1 = plan->d_fam_tw;
-    fa.twa = plan->d_fam_tw + (size_t)kFamRows * f.h;
+    fa.twa = plan->d_fam_tw + (size_t)f.rows * f.h;
     fa.win = plan->d_win;
     fa.mom = momentum / (1.f + momentum);
     fa.seed = seed;
@@ -1127,7 +1127,7 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
       fa.Lw = Lw;
       fa.fs_plain = plan->gg.fs;
       fa.tw1 = plan->d_fam_tw;
-      fa.twa = plan->d_fam_tw + (size_t)kFamRows * f.h;
+      fa.twa = plan->d_fam_tw + (size_t)f.rows * f.h;
       fa.win = plan->d_win;
       fa.B = B;
       fa.T = T;

@@ -26,10 +26,10 @@
 
 namespace rfx {
 
-constexpr int fam_threads(int ra, int rb) {
+constexpr int fam_threads(int ra, int rb, int nr = 40) {
   int n = ra * rb;
-  if (kFamRows * rb > n) n = kFamRows * rb;
-  if (kFamRows * ra > n) n = kFamRows * ra;
+  if ((nr / 2 + 1) * rb > n) n = (nr / 2 + 1) * rb;
+  if ((nr / 2 + 1) * ra > n) n = (nr / 2 + 1) * ra;
   return (n + 63) / 64 * 64;
 }
 
@@ -53,7 +53,7 @@ constexpr int fam_threads(int ra, int rb) {
 #endif
 
 bool fam_row_stride_even(const FamGeom& g) { return RFX_FAM_VEC && g.rb % 2 == 0; }
-size_t fam_lds_bytes(const FamGeom& g) { return sizeof(cf) * (size_t)kFamRows * g.rs; }
+size_t fam_lds_bytes(const FamGeom& g) { return sizeof(cf) * (size_t)g.rows * g.rs; }
 
 // Where the pass-A twiddles W_h^{i p} live: in LDS (a static array next to the cube: the compiler then knows that cube stores
 // never alias twiddle reads) wherever two workgroups still share a CU with it - every geometry but 48 kHz, whose cube leaves
@@ -89,26 +89,28 @@ struct FamTwA {
 //   frame's P1 use the same values), and the next frame's ten input samples
 // Phases are fenced for the compiler's scheduler (left alone it hoists the next phase's loads over the current butterfly and
 // spills 70 registers).
-template <int MODE, int RA, int RB>
-__global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_waves_per_eu(4))) fam_gl_kernel(FamGlArgs a) {
+template <int MODE, int RA, int RB, int NR = 40>
+__global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu_waves_per_eu(4))) fam_gl_kernel(FamGlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* cube = reinterpret_cast<cf*>(smem);
   constexpr int H = RA * RB;
-  constexpr int NT = fam_threads(RA, RB);
+  constexpr int NT = fam_threads(RA, RB, NR);
+  constexpr int ROWS = NR / 2 + 1, WH = NR / 4;  // rows of the cube, window blocks of h samples (rfx_fam_core.h)
   const int tid = threadIdx.x;
   const int rs = a.g.rs;
   const bool act1 = tid < H;
   const int npr = act1 ? tid : H - 1;  // idle lanes shadow the last active one (loads only, never stores)
-  const bool actA = tid < kFamRows * RB;
-  const int tA = actA ? tid : kFamRows * RB - 1;
+  const int col = NR == 40 ? npr : (npr + a.g.left) % H;  // cube column of this thread's window samples
+  const bool actA = tid < ROWS * RB;
+  const int tA = actA ? tid : ROWS * RB - 1;
   const int rowA = tA / RB, iA = tA - rowA * RB;
-  const bool actB = tid < kFamRows * RA;
-  const int tB = actB ? tid : kFamRows * RA - 1;
+  const bool actB = tid < ROWS * RA;
+  const int tB = actB ? tid : ROWS * RA - 1;
   const int rowB = tB / RA, pB = tB - rowB * RA;
   cf* const rowa = cube + rowA * rs + iA;
   cf* const rowb = cube + rowB * rs + pB * RB;
-  const rsrc_t tw1 = make_rsrc(a.tw1, (size_t)kFamRows * H * sizeof(cf));
-  const rsrc_t win = make_rsrc(a.win, (size_t)10 * H * sizeof(float));
+  const rsrc_t tw1 = make_rsrc(a.tw1, (size_t)ROWS * H * sizeof(cf));
+  const rsrc_t win = make_rsrc(a.win, (size_t)WH * H * sizeof(float));
   const unsigned npr4 = (unsigned)npr * 4u, npr8 = (unsigned)npr * 8u, tB4 = (unsigned)tB * 4u;
   const float oscale = 2.0f / (float)a.g.n_fft;
   const long long nframes = (long long)a.B * a.T;
@@ -125,26 +127,26 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
   wa.tab = twa_lds + iA * (RA - 1);
   // g(n')^k1 for k1 = 1..10 and 20 only (fam_g_pow)
   cf w1[12];
-  float wv[10], u[10], pv[10];
+  float wv[WH], u[WH], pv[WH];
   auto load_tables = [&] {
 #pragma unroll
-    for (int k = 1; k <= 11; ++k) {
+    for (int k = 1; k <= (NR == 40 ? 11 : 10); ++k) {
       const v2f t = ld2(tw1, npr8, (unsigned)(k <= 10 ? k : 20) * (H * 8u));
       w1[k] = cf{t.x, t.y};
     }
 #pragma unroll
-    for (int j = 0; j < 10; ++j) wv[j] = ld1(win, npr4, (unsigned)j * (H * 4u));
+    for (int j = 0; j < WH; ++j) wv[j] = ld1(win, npr4, (unsigned)j * (H * 4u));
   };
   auto g1 = [&w1](int k) { return fam_g_pow(w1, k); };
   // frame fr is centred on sample hop * fr of the reflect-padded estimate (torch.stft center=True): the window covers
-  // positions hop * fr - 5 h .. hop * fr + 5 h - 1
+  // positions hop * fr + off .. hop * fr + off + win - 1, off = left - n_fft / 2 (-5 h in the 40 h family)
   auto load_samples = [&](long long gf) {
     const int clip = (int)(gf / a.T), fr = (int)(gf - (long long)clip * a.T);
     const rsrc_t xc = make_rsrc(a.x_cur + (size_t)clip * a.audio_stride, (size_t)a.L * sizeof(float));
     const rsrc_t xp = make_rsrc(a.x_prev + (size_t)clip * a.audio_stride, (size_t)a.L * sizeof(float));
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const unsigned p4 = (unsigned)reflect_index(a.g.hop * fr + (j - 5) * H + npr, a.L) * 4u;
+    for (int j = 0; j < WH; ++j) {
+      const unsigned p4 = (unsigned)reflect_index(a.g.hop * fr + a.g.off + j * H + npr, a.L) * 4u;
       u[j] = ld1(xc, p4, 0);
       if (MODE == 2) pv[j] = ld1(xp, p4, 0);
     }
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
   // u = (x_k - m x_{k-1}) * window, formed as soon as the samples are in (ten registers across P1' instead of twenty)
   auto window_samples = [&] {
 #pragma unroll
-    for (int j = 0; j < 10; ++j) u[j] = (MODE == 2 ? fmaf(-a.mom, pv[j], u[j]) : u[j]) * wv[j];
+    for (int j = 0; j < WH; ++j) u[j] = (MODE == 2 ? fmaf(-a.mom, pv[j], u[j]) : u[j]) * wv[j];
   };
   if (MODE != 0 && (long long)blockIdx.x < nframes) {
     load_tables();
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
     cf R[RB];
     FSTAMP(0);
     if (MODE != 0) {
-      if (act1) fam_p1_forward_store(u, g1, cube, npr, rs);
+      if (act1) fam_p1_forward_store<NR>(u, g1, cube, col, rs);
       RFX_SCHED_FENCE();
       wa.template load<0>();
 #if RFX_FAM_TW_EARLY
@@ -241,12 +243,12 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
     if (more) load_samples(gf + gridDim.x);
     RFX_SCHED_FENCE();
     {
-      float y[10];
-      fam_p1_load_inverse(cube, g1, y, npr, rs);
+      float y[WH];
+      fam_p1_load_inverse<NR>(cube, g1, y, col, rs);
       if (act1) {
-        const rsrc_t out = make_rsrc(a.frames + (size_t)gf * a.g.win, (size_t)10 * H * sizeof(float));
+        const rsrc_t out = make_rsrc(a.frames + (size_t)gf * a.g.win, (size_t)WH * H * sizeof(float));
 #pragma unroll
-        for (int j = 0; j < 10; ++j) st1<RFX_FAM_STORE_AUX>(y[j] * (wv[j] * oscale), out, npr4, (unsigned)j * (H * 4u));
+        for (int j = 0; j < WH; ++j) st1<RFX_FAM_STORE_AUX>(y[j] * (wv[j] * oscale), out, npr4, (unsigned)j * (H * 4u));
       }
     }
     RFX_SCHED_FENCE();
@@ -272,29 +274,31 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
 // A / B as above; the frame then changes places through LDS - once every row has been read the cube's memory becomes the
 // bin-ordered frame, each bin written by its primary slot (the direct one where a bin has two) - and leaves in whole lines, in
 // the plan's plain layout [B*T][fs] (what rfx_stft hands out and gen_mel_kernel reads).  MODE 0: |X|, MODE 1: X.
-template <int MODE, int RA, int RB>
-__global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_waves_per_eu(4))) fam_fwd_kernel(FamFwdArgs a) {
+template <int MODE, int RA, int RB, int NR = 40>
+__global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu_waves_per_eu(4))) fam_fwd_kernel(FamFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* cube = reinterpret_cast<cf*>(smem);
   float* magl = reinterpret_cast<float*>(smem);
   constexpr int H = RA * RB;
-  constexpr int NT = fam_threads(RA, RB);
+  constexpr int NT = fam_threads(RA, RB, NR);
+  constexpr int ROWS = NR / 2 + 1, WH = NR / 4;
   constexpr bool VEC = RFX_FAM_VEC && RB % 2 == 0;
   constexpr bool TWL = fam_twiddles_in_lds(RA, RB);
   const int tid = threadIdx.x;
   const int rs = a.g.rs;
   const bool act1 = tid < H;
   const int npr = act1 ? tid : H - 1;
-  const bool actA = tid < kFamRows * RB;
-  const int tA = actA ? tid : kFamRows * RB - 1;
+  const int col = NR == 40 ? npr : (npr + a.g.left) % H;
+  const bool actA = tid < ROWS * RB;
+  const int tA = actA ? tid : ROWS * RB - 1;
   const int rowA = tA / RB, iA = tA - rowA * RB;
-  const bool actB = tid < kFamRows * RA;
-  const int tB = actB ? tid : kFamRows * RA - 1;
+  const bool actB = tid < ROWS * RA;
+  const int tB = actB ? tid : ROWS * RA - 1;
   const int rowB = tB / RA, pB = tB - rowB * RA;
   cf* const rowa = cube + rowA * rs + iA;
   cf* const rowb = cube + rowB * rs + pB * RB;
-  const rsrc_t tw1 = make_rsrc(a.tw1, (size_t)kFamRows * H * sizeof(cf));
-  const rsrc_t win = make_rsrc(a.win, (size_t)10 * H * sizeof(float));
+  const rsrc_t tw1 = make_rsrc(a.tw1, (size_t)ROWS * H * sizeof(cf));
+  const rsrc_t win = make_rsrc(a.win, (size_t)WH * H * sizeof(float));
   const unsigned npr4 = (unsigned)npr * 4u, npr8 = (unsigned)npr * 8u;
   const long long nframes = (long long)a.B * a.T;
   const int fs = a.fs_plain, n_stft = a.g.n_stft;
@@ -308,27 +312,27 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
   wa.voff = (unsigned)iA * ((RA - 1) * 8u);
   wa.tab = twa_lds + iA * (RA - 1);
   cf w1[12];
-  float wv[10], u[10];
+  float wv[WH], u[WH];
   auto g1 = [&w1](int k) { return fam_g_pow(w1, k); };
-  auto load_frame_inputs = [&](long long gf) {  // tables and the frame's ten samples (reflect-padded like torch.stft center=True)
+  auto load_frame_inputs = [&](long long gf) {  // tables and the frame's samples (reflect-padded like torch.stft center=True)
 #pragma unroll
-    for (int k = 1; k <= 11; ++k) {
+    for (int k = 1; k <= (NR == 40 ? 11 : 10); ++k) {
       const v2f t = ld2(tw1, npr8, (unsigned)(k <= 10 ? k : 20) * (H * 8u));
       w1[k] = cf{t.x, t.y};
     }
     const int clip = (int)(gf / a.T), fr = (int)(gf - (long long)clip * a.T);
     const rsrc_t x = make_rsrc(a.wave + (size_t)clip * a.wave_stride, (size_t)a.Lw * sizeof(float));
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
+    for (int j = 0; j < WH; ++j) {
       wv[j] = ld1(win, npr4, (unsigned)j * (H * 4u));
-      u[j] = ld1(x, (unsigned)reflect_index(a.g.hop * fr + (j - 5) * H + npr, a.Lw) * 4u, 0);
+      u[j] = ld1(x, (unsigned)reflect_index(a.g.hop * fr + a.g.off + j * H + npr, a.Lw) * 4u, 0);
     }
   };
   if ((long long)blockIdx.x < nframes) load_frame_inputs(blockIdx.x);
   for (long long gf = blockIdx.x; gf < nframes; gf += gridDim.x) {
 #pragma unroll
-    for (int j = 0; j < 10; ++j) u[j] *= wv[j];
-    if (act1) fam_p1_forward_store(u, g1, cube, npr, rs);
+    for (int j = 0; j < WH; ++j) u[j] *= wv[j];
+    if (act1) fam_p1_forward_store<NR>(u, g1, cube, col, rs);
     RFX_SCHED_FENCE();
     wa.template load<0>();
     __syncthreads();
@@ -349,14 +353,14 @@ __global__ void __launch_bounds__(fam_threads(RA, RB)) __attribute__((amdgpu_wav
       // slot s of this thread holds k = k0 + 40 RA s.  k0 is frame-invariant, and the compiler would hoist all RB bin positions
       // and conjugate flags out of the frame loop - into scratch at the 128-register bound (68 spilled registers in round 3):
       // the empty asm makes k0 opaque per frame, two integer instructions per slot instead
-      int k0 = rowB + 40 * pB;
+      int k0 = rowB + NR * pB;
       asm volatile("" : "+v"(k0));
 #pragma unroll
       for (int s = 0; s < RB; ++s) {
-        const int k = k0 + 40 * RA * s;
+        const int k = k0 + NR * RA * s;
         const bool cj = k > a.g.n_fft / 2;
         const int bin = cj ? a.g.n_fft - k : k;
-        if (fam_slot_is_primary(rowB, cj)) {  // rows 0 and 20 hold their bins twice: the direct slot writes
+        if (fam_slot_is_primary(NR, rowB, cj)) {  // rows 0 and 20 hold their bins twice: the direct slot writes
           if (MODE == 1) cube[bin] = cf{R[s].re, cj ? -R[s].im : R[s].im};
           // v_sqrt_f32 (1 ulp) instead of the IEEE expansion: |X| carries ~1e-7 relative error from the transform anyway
           else magl[bin] = __builtin_amdgcn_sqrtf(fmaf(R[s].re, R[s].re, R[s].im * R[s].im));
@@ -419,11 +423,12 @@ __global__ void __launch_bounds__(512) fam_repack_kernel(const float* __restrict
 }
 
 using FamGlFn = void (*)(FamGlArgs);
-template <int RA, int RB>
+template <int RA, int RB, int NR = 40>
 static FamGlFn fam_fn(int mode) {
-  return mode == 0 ? fam_gl_kernel<0, RA, RB> : mode == 1 ? fam_gl_kernel<1, RA, RB> : fam_gl_kernel<2, RA, RB>;
+  return mode == 0 ? fam_gl_kernel<0, RA, RB, NR> : mode == 1 ? fam_gl_kernel<1, RA, RB, NR> : fam_gl_kernel<2, RA, RB, NR>;
 }
 static FamGlFn fam_fn(const FamGeom& g, int mode) {
+  if (g.nrad == 20) return g.h == 441 ? fam_fn<21, 21, 20>(mode) : nullptr;  // 22.05 kHz
   switch (g.h) {
     case 80: return fam_fn<10, 8>(mode);
     case 160: return fam_fn<16, 10>(mode);
@@ -436,11 +441,12 @@ static FamGlFn fam_fn(const FamGeom& g, int mode) {
 }
 
 using FamFwdFn = void (*)(FamFwdArgs);
-template <int RA, int RB>
+template <int RA, int RB, int NR = 40>
 static FamFwdFn fam_fwd_fn(int mode) {
-  return mode == 0 ? fam_fwd_kernel<0, RA, RB> : mode == 1 ? fam_fwd_kernel<1, RA, RB> : fam_fwd_kernel<2, RA, RB>;
+  return mode == 0 ? fam_fwd_kernel<0, RA, RB, NR> : mode == 1 ? fam_fwd_kernel<1, RA, RB, NR> : fam_fwd_kernel<2, RA, RB, NR>;
 }
 static FamFwdFn fam_fwd_fn(const FamGeom& g, int mode) {
+  if (g.nrad == 20) return g.h == 441 ? fam_fwd_fn<21, 21, 20>(mode) : nullptr;  // 22.05 kHz
   switch (g.h) {
     case 80: return fam_fwd_fn<10, 8>(mode);
     case 160: return fam_fwd_fn<16, 10>(mode);

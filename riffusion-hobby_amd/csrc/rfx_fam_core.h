@@ -21,15 +21,25 @@
 
 namespace rfx {
 
-constexpr int kFamRows = 21;
+constexpr int kFamRows = 21;  // rows of the 40 h family (the 20 h family keeps 11)
 
+// Round 4: the same machinery for n_fft = 20 h, win_length = 5 h - 22.05 kHz at the reference's default durations
+// (8820 / 2205 / 220 with h = 441: the window is not ten "hops", spectrogram_params.py:62-81).  With N = nrad h and the window
+// sample i = h j + m (m < h, j < nrad / 4) at frame position left + i, left = (n_fft - win_length) / 2 as torch.stft centres it:
+//   X[k1 + nrad k'] = sum_m w_h^{n'' k'} g(m)^{k1} sum_j u[h j + m] w_nrad^{j k1},   g(m) = exp(-2 pi i (m + left) / N),
+// n'' = (m + left) mod h the cube column of thread m.  P1 is a pruned nrad-point transform of nrad / 4 reals keeping the rows
+// k1 = 0 .. nrad / 2; rows 0 and nrad / 2 hold their bins twice.  (40 h family: left = 15 h, so n'' = m: nothing changes.)
 struct FamGeom {
-  int h;         // n_fft / 40 = win_length / 10
+  int h;         // n_fft / nrad = win_length / (nrad / 4)
   int ra, rb;    // h = ra * rb
-  int nthr;      // threads per workgroup: max(h, 21 rb, 21 ra) rounded up to whole waves
+  int nthr;      // threads per workgroup: max(h, rows rb, rows ra) rounded up to whole waves
   int rs;        // LDS elements between rows of the cube (>= h)
   int fsf;       // floats per frame of the slot-ordered magnitudes: rb * nthr (thread t's slot s at s * nthr + t)
   int n_fft, win, hop, n_stft;
+  int nrad;      // 40 or 20: length of the pruned first transform
+  int rows;      // nrad / 2 + 1 rows of h points
+  int left;      // frame position of the first window sample, (n_fft - win) / 2
+  int off;       // left - n_fft / 2: signal position of window sample 0 of frame 0 (before reflection)
 };
 
 // the digit pairs the kernels are instantiated for (both digits implemented by gen_dft)
@@ -45,16 +55,22 @@ RFX_HD bool fam_digits(int h, int* ra, int* rb) {
   }
 }
 RFX_HD bool fam_make_geom(int n_fft, int win, int hop, FamGeom* g) {
-  if (n_fft % 40 != 0 || win * 4 != n_fft || win % 10 != 0 || hop < 1) return false;
-  const int h = n_fft / 40;
+  if (win * 4 != n_fft || hop < 1) return false;
+  int nrad = 0;
+  if (n_fft % 40 == 0 && win % 10 == 0) nrad = 40;
+  else if (n_fft % 20 == 0 && win % 5 == 0 && n_fft / 20 == 441) nrad = 20;  // 22.05 kHz: the one 20 h geometry instantiated
+  if (!nrad) return false;
+  const int h = n_fft / nrad;
   int ra, rb;
   if (!fam_digits(h, &ra, &rb)) return false;
   g->h = h;
   g->ra = ra;
   g->rb = rb;
+  g->nrad = nrad;
+  g->rows = nrad / 2 + 1;
   int n = h;
-  if (kFamRows * rb > n) n = kFamRows * rb;
-  if (kFamRows * ra > n) n = kFamRows * ra;
+  if (g->rows * rb > n) n = g->rows * rb;
+  if (g->rows * ra > n) n = g->rows * ra;
   g->nthr = (n + 63) / 64 * 64;
   g->rs = h;
   g->fsf = rb * g->nthr;
@@ -62,33 +78,92 @@ RFX_HD bool fam_make_geom(int n_fft, int win, int hop, FamGeom* g) {
   g->win = win;
   g->hop = hop;
   g->n_stft = n_fft / 2 + 1;
+  g->left = (n_fft - win) / 2;
+  g->off = g->left - n_fft / 2;
   return true;
 }
 // bin held by slot s of pass-B thread (row k1, p); *conj_out set when the slot holds the conjugate of that bin
 RFX_HD int fam_slot_bin(const FamGeom& g, int k1, int p, int s, bool* conj_out) {
-  const int k = k1 + 40 * (p + g.ra * s);
+  const int k = k1 + g.nrad * (p + g.ra * s);
   const bool c = k > g.n_fft / 2;
   if (conj_out) *conj_out = c;
   return c ? g.n_fft - k : k;
 }
 
 // g(n')^k1 from the eleven values a thread keeps, w[1..10] = g^1 .. g^10 and w[11] = g^20: g^(20-k) = g^20 conj(g^k) - one more
-// complex product for the rows 11..19 instead of nine more table loads per frame and eighteen registers
+// complex product for the rows 11..19 instead of nine more table loads per frame and eighteen registers.  (20 h family: the
+// ten rows 1..10 are the ten values.)
 RFX_HD cf fam_g_pow(const cf (&w)[12], int k) { return k <= 10 ? w[k] : k == 20 ? w[11] : cmulc(w[11], w[20 - k]); }
 
-// Which slot writes a bin when the frame leaves in bin order (forward kernel): bins with k mod 40 in 21..39 exist as a conjugate
-// slot only, bins on rows 0 and 20 exist twice (the slot k and the slot n_fft - k): the direct one writes
-RFX_HD bool fam_slot_is_primary(int k1, bool conj) { return !conj || (k1 != 0 && k1 != 20); }
+// Which slot writes a bin when the frame leaves in bin order (forward kernel): bins with k mod nrad above nrad / 2 exist as a
+// conjugate slot only, bins on rows 0 and nrad / 2 exist twice (the slot k and the slot n_fft - k): the direct one writes
+RFX_HD bool fam_slot_is_primary(int nrad, int k1, bool conj) { return !conj || (k1 != 0 && k1 != nrad / 2); }
 
-// ---- P1: thread n' < h.  tw1(k1) = g(n')^k1
-template <class TW>
-RFX_HD void fam_p1_forward_store(const float (&u)[10], TW tw1, cf* cube, int npr, int rs) {
-  p1_forward_rows(u, [&](int k1, cf v) { cube[k1 * rs + npr] = k1 == 0 ? v : cmul(v, tw1(k1)); });
+// ---- the pruned first transform of the 20 h family: v[k] = sum_{j=0..4} u[j] w20^{j k}, k = 0..10 (u real, w20 = exp(-2 pi i / 20)).
+// Even / odd j:  Ee[k] = u0 + u2 w^{2k} + u4 w^{4k},  Eo[k] = u1 w^k + u3 w^{3k};  v[k] = Ee + Eo and, because
+// w^{j (10 - k)} = (-1)^j conj(w^{j k}),  v[10 - k] = conj(Ee - Eo): only k = 1..4 need the trigonometric sums.
+template <class PUT>
+RFX_HD void p1_forward_rows20(const float (&u)[5], PUT put) {
+  constexpr float C40[40] = RFX_C40F_TABLE;  // cos / sin of 2 pi i / 40: the 20th roots are the even entries
+  constexpr float S40[40] = RFX_S40F_TABLE;
+  {
+    const float ee = u[0] + u[2] + u[4], eo = u[1] + u[3];
+    put(0, cf{ee + eo, 0.f});
+    put(10, cf{ee - eo, 0.f});
+    put(5, cf{u[0] - u[2] + u[4], u[3] - u[1]});  // w20^5 = -i
+  }
+#pragma unroll
+  for (int k = 1; k <= 4; ++k) {
+    const float eer = fmaf(C40[(8 * k) % 40], u[4], fmaf(C40[(4 * k) % 40], u[2], u[0]));
+    const float eei = -fmaf(S40[(8 * k) % 40], u[4], S40[(4 * k) % 40] * u[2]);
+    const float eor = fmaf(C40[(6 * k) % 40], u[3], C40[(2 * k) % 40] * u[1]);
+    const float eoi = -fmaf(S40[(6 * k) % 40], u[3], S40[(2 * k) % 40] * u[1]);
+    put(k, cf{eer + eor, eei + eoi});
+    put(10 - k, cf{eer - eor, -(eei - eoi)});
+  }
+}
+// inverse: y[j] = 0.5 (V0.re + (-1)^j V10.re) + sum_{k=1..9} Re(V[k] w20^{-k j}), j = 0..4 (the caller folds 2 / N and the
+// synthesis window into one multiplier).  Rows k and 10 - k pair up: w20^{-(10-k) j} = (-1)^j conj(w20^{-k j}), so
+// B[k] = V[k] + conj(V[10-k]) feeds the even outputs and D[k] = V[k] - conj(V[10-k]) the odd ones.
+template <class RAW, class FIX>
+RFX_HD void p1_inverse_rows20(RAW raw, FIX fix, float (&y)[5]) {
+  constexpr float C40[40] = RFX_C40F_TABLE;
+  constexpr float S40[40] = RFX_S40F_TABLE;
+  {
+    const cf V0 = fix(0, raw(0)), V10 = fix(10, raw(10)), V5 = fix(5, raw(5));
+    const float he = 0.5f * (V0.re + V10.re), ho = 0.5f * (V0.re - V10.re);
+    y[0] = he + V5.re;   // Re(V5 i^j): +re, -im, -re, +im, +re
+    y[1] = ho - V5.im;
+    y[2] = he - V5.re;
+    y[3] = ho + V5.im;
+    y[4] = he + V5.re;
+  }
+#pragma unroll
+  for (int k = 1; k <= 4; ++k) {
+    const cf Vk = fix(k, raw(k)), Vm = fix(10 - k, raw(10 - k));
+    const cf B{Vk.re + Vm.re, Vk.im - Vm.im}, D{Vk.re - Vm.re, Vk.im + Vm.im};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const cf z = (j & 1) ? D : B;  // Re(z w20^{-k j}) = z.re cos(2 pi k j / 20) - z.im sin(2 pi k j / 20)
+      y[j] = fmaf(-S40[(2 * k * j) % 40], z.im, fmaf(C40[(2 * k * j) % 40], z.re, y[j]));
+    }
+  }
+}
+
+// ---- P1: thread m < h, cube column `col` = (m + left) mod h.  tw1(k1) = g(m)^k1
+template <int NR, class TW>
+RFX_HD void fam_p1_forward_store(const float (&u)[NR / 4], TW tw1, cf* cube, int col, int rs) {
+  auto put = [&](int k1, cf v) { cube[k1 * rs + col] = k1 == 0 ? v : cmul(v, tw1(k1)); };
+  if constexpr (NR == 40) p1_forward_rows(u, put);
+  else p1_forward_rows20(u, put);
 }
 // un-normalised: the caller multiplies by 2 / n_fft (and the synthesis window)
-template <class TW>
-RFX_HD void fam_p1_load_inverse(const cf* cube, TW tw1, float (&y)[10], int npr, int rs) {
-  p1_inverse_rows([&](int k1) { return cube[k1 * rs + npr]; }, [&](int k1, cf c) { return k1 == 0 ? c : cmulc(c, tw1(k1)); }, y);
+template <int NR, class TW>
+RFX_HD void fam_p1_load_inverse(const cf* cube, TW tw1, float (&y)[NR / 4], int col, int rs) {
+  auto raw = [&](int k1) { return cube[k1 * rs + col]; };
+  auto fix = [&](int k1, cf c) { return k1 == 0 ? c : cmulc(c, tw1(k1)); };
+  if constexpr (NR == 40) p1_inverse_rows(raw, fix, y);
+  else p1_inverse_rows20(raw, fix, y);
 }
 
 // ---- pass A: thread (row, i).  tw(p) = W_h^{i p}, p = 1..RA-1.  `stage(0)` runs once the row values are requested and

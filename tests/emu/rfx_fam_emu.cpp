@@ -13,10 +13,10 @@ struct FamTables {
 };
 void make_tables(const FamGeom& g, FamTables& t) {
   const double PI2 = 6.283185307179586476925286766559;
-  t.tw1.resize((size_t)kFamRows * g.h);
-  for (int k1 = 0; k1 < kFamRows; ++k1)
+  t.tw1.resize((size_t)g.rows * g.h);
+  for (int k1 = 0; k1 < g.rows; ++k1)
     for (int n = 0; n < g.h; ++n) {
-      const long long e = ((long long)k1 * (n + 15 * g.h)) % g.n_fft;
+      const long long e = ((long long)k1 * (n + g.left)) % g.n_fft;
       t.tw1[(size_t)k1 * g.h + n] = cf{(float)cos(PI2 * (double)e / g.n_fft), (float)(-sin(PI2 * (double)e / g.n_fft))};
     }
   t.twa.resize((size_t)g.rb * (g.ra - 1));
@@ -26,59 +26,61 @@ void make_tables(const FamGeom& g, FamTables& t) {
       t.twa[(size_t)i * (g.ra - 1) + p - 1] = cf{(float)cos(PI2 * e / (double)g.h), (float)(-sin(PI2 * e / (double)g.h))};
     }
 }
-template <int RA, int RB>
+template <int RA, int RB, int NR>
 void forward(const FamGeom& g, const FamTables& t, const float* win_samples, std::vector<cf>& slots) {
-  std::vector<cf> cube((size_t)kFamRows * g.rs);
+  constexpr int ROWS = NR / 2 + 1, WH = NR / 4;
+  std::vector<cf> cube((size_t)ROWS * g.rs);
   for (int n = 0; n < g.h; ++n) {  // P1
-    float u[10];
-    for (int j = 0; j < 10; ++j) u[j] = win_samples[j * g.h + n];
-    cf w[12];  // what a thread of the kernel holds: g^1 .. g^10 and g^20
-    for (int k = 1; k <= 11; ++k) w[k] = t.tw1[(size_t)(k <= 10 ? k : 20) * g.h + n];
-    fam_p1_forward_store(u, [&](int k1) { return fam_g_pow(w, k1); }, cube.data(), n, g.rs);
+    float u[WH];
+    for (int j = 0; j < WH; ++j) u[j] = win_samples[j * g.h + n];
+    cf w[12];  // what a thread of the kernel holds: g^1 .. g^10 and (40 h family) g^20
+    for (int k = 1; k <= (NR == 40 ? 11 : 10); ++k) w[k] = t.tw1[(size_t)(k <= 10 ? k : 20) * g.h + n];
+    fam_p1_forward_store<NR>(u, [&](int k1) { return fam_g_pow(w, k1); }, cube.data(), (n + g.left) % g.h, g.rs);
   }
-  for (int tid = 0; tid < kFamRows * RB; ++tid) {  // pass A
+  for (int tid = 0; tid < ROWS * RB; ++tid) {  // pass A
     const int row = tid / RB, i = tid % RB;
     fam_pass_a_forward<RA, RB>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)i * (RA - 1) + p - 1]; });
   }
   slots.assign((size_t)g.fsf, cf{0.f, 0.f});
-  for (int tid = 0; tid < kFamRows * RA; ++tid) {  // pass B
+  for (int tid = 0; tid < ROWS * RA; ++tid) {  // pass B
     const int row = tid / RA, p = tid % RA;
     cf R[RB];
     fam_pass_b_forward<RA, RB>(cube.data() + (size_t)row * g.rs, p, R);
     for (int s = 0; s < RB; ++s) slots[(size_t)s * g.nthr + tid] = R[s];
   }
 }
-template <int RA, int RB>
+template <int RA, int RB, int NR>
 void inverse(const FamGeom& g, const FamTables& t, const std::vector<cf>& slots, float* win_samples) {
-  std::vector<cf> cube((size_t)kFamRows * g.rs);
-  for (int tid = 0; tid < kFamRows * RA; ++tid) {
+  constexpr int ROWS = NR / 2 + 1, WH = NR / 4;
+  std::vector<cf> cube((size_t)ROWS * g.rs);
+  for (int tid = 0; tid < ROWS * RA; ++tid) {
     const int row = tid / RA, p = tid % RA;
     cf Z[RB];
     for (int s = 0; s < RB; ++s) Z[s] = slots[(size_t)s * g.nthr + tid];
     fam_pass_b_inverse<RA, RB>(cube.data() + (size_t)row * g.rs, p, Z);
   }
-  for (int tid = 0; tid < kFamRows * RB; ++tid) {
+  for (int tid = 0; tid < ROWS * RB; ++tid) {
     const int row = tid / RB, i = tid % RB;
     fam_pass_a_inverse<RA, RB>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)i * (RA - 1) + p - 1]; });
   }
   const float sc = 2.0f / (float)g.n_fft;
   for (int n = 0; n < g.h; ++n) {
-    float y[10];
+    float y[WH];
     cf w[12];
-    for (int k = 1; k <= 11; ++k) w[k] = t.tw1[(size_t)(k <= 10 ? k : 20) * g.h + n];
-    fam_p1_load_inverse(cube.data(), [&](int k1) { return fam_g_pow(w, k1); }, y, n, g.rs);
-    for (int j = 0; j < 10; ++j) win_samples[j * g.h + n] = y[j] * sc;
+    for (int k = 1; k <= (NR == 40 ? 11 : 10); ++k) w[k] = t.tw1[(size_t)(k <= 10 ? k : 20) * g.h + n];
+    fam_p1_load_inverse<NR>(cube.data(), [&](int k1) { return fam_g_pow(w, k1); }, y, (n + g.left) % g.h, g.rs);
+    for (int j = 0; j < WH; ++j) win_samples[j * g.h + n] = y[j] * sc;
   }
 }
-template <int RA, int RB>
+template <int RA, int RB, int NR = 40>
 int run(const FamGeom& g, int dir, const float* in, float* out) {
   FamTables t;
   make_tables(g, t);
   std::vector<cf> slots;
   if (dir == 0) {  // in: the win windowed samples of a frame; out: one-sided spectrum (n_fft/2 + 1 complex), duplicates checked
-    forward<RA, RB>(g, t, in, slots);
+    forward<RA, RB, NR>(g, t, in, slots);
     std::vector<int> seen(g.n_stft, 0);
-    for (int k1 = 0; k1 < kFamRows; ++k1)
+    for (int k1 = 0; k1 < g.rows; ++k1)
       for (int p = 0; p < RA; ++p)
         for (int s = 0; s < RB; ++s) {
           bool cj;
@@ -100,14 +102,14 @@ int run(const FamGeom& g, int dir, const float* in, float* out) {
   }
   // in: one-sided spectrum; out: the win samples the window covers of its inverse real FFT
   slots.assign((size_t)g.fsf, cf{0.f, 0.f});
-  for (int k1 = 0; k1 < kFamRows; ++k1)
+  for (int k1 = 0; k1 < g.rows; ++k1)
     for (int p = 0; p < RA; ++p)
       for (int s = 0; s < RB; ++s) {
         bool cj;
         const int bin = fam_slot_bin(g, k1, p, s, &cj);
         slots[(size_t)s * g.nthr + k1 * RA + p] = cf{in[2 * bin], cj ? -in[2 * bin + 1] : in[2 * bin + 1]};
       }
-  inverse<RA, RB>(g, t, slots, out);
+  inverse<RA, RB, NR>(g, t, slots, out);
   return 0;
 }
 }  // namespace
@@ -118,6 +120,7 @@ int emu_fam_transform(int n_fft, int dir, int rs_pad, const float* in, float* ou
   FamGeom g;
   if (!fam_make_geom(n_fft, n_fft / 4, n_fft / 40, &g)) return -1;
   g.rs += rs_pad;
+  if (g.nrad == 20) return g.h == 441 ? run<21, 21, 20>(g, dir, in, out) : -1;
   switch (g.h) {
     case 80: return run<10, 8>(g, dir, in, out);
     case 160: return run<16, 10>(g, dir, in, out);
@@ -133,12 +136,12 @@ int emu_fam_primary_writers(int n_fft, int* count /* [n_fft / 2 + 1] */) {
   FamGeom g;
   if (!fam_make_geom(n_fft, n_fft / 4, n_fft / 40, &g)) return -1;
   for (int b = 0; b < g.n_stft; ++b) count[b] = 0;
-  for (int k1 = 0; k1 < kFamRows; ++k1)
+  for (int k1 = 0; k1 < g.rows; ++k1)
     for (int p = 0; p < g.ra; ++p)
       for (int s = 0; s < g.rb; ++s) {
         bool cj;
         const int bin = fam_slot_bin(g, k1, p, s, &cj);
-        if (fam_slot_is_primary(k1, cj)) count[bin]++;
+        if (fam_slot_is_primary(g.nrad, k1, cj)) count[bin]++;
       }
   return 0;
 }
@@ -155,7 +158,7 @@ int emu_fam_geom(int n_fft, int win, int hop, int* out6) {
 // slot, synthesises; the windowed frames are overlap-added and divided by the window envelope.  Host arithmetic (exact sqrt and
 // divide in gl_project where the device uses v_rsq_f32).
 namespace {
-template <int RA, int RB>
+template <int RA, int RB, int NR = 40>
 int gl_run(const FamGeom& g, int T, int n_iter, float momentum, const float* mag, const float* ang, const float* win, float* out) {
   FamTables t;
   make_tables(g, t);
@@ -175,13 +178,13 @@ int gl_run(const FamGeom& g, int T, int n_iter, float momentum, const float* mag
         slots.assign((size_t)g.fsf, cf{0.f, 0.f});
       } else {
         for (int j = 0; j < g.win; ++j) {
-          const int p = reflect_index(g.hop * fr + j - 5 * g.h, L);
+          const int p = reflect_index(g.hop * fr + j + g.off, L);
           const float x = it >= 2 ? fmaf(-m, xp[p], xc[p]) : xc[p];
           u[j] = x * win[j];
         }
-        forward<RA, RB>(g, t, u.data(), slots);
+        forward<RA, RB, NR>(g, t, u.data(), slots);
       }
-      for (int k1 = 0; k1 < kFamRows; ++k1)
+      for (int k1 = 0; k1 < g.rows; ++k1)
         for (int p = 0; p < RA; ++p)
           for (int s2 = 0; s2 < RB; ++s2) {
             bool cj;
@@ -195,13 +198,13 @@ int gl_run(const FamGeom& g, int T, int n_iter, float momentum, const float* mag
               z = gl_project(z, S);
             }
           }
-      inverse<RA, RB>(g, t, slots, y.data());
+      inverse<RA, RB, NR>(g, t, slots, y.data());
       for (int j = 0; j < g.win; ++j) frames[(size_t)fr * g.win + j] = y[j] * sc * win[j];
     }
     // gen_fold_kernel: sample p of the output sits at P = p + n_fft/2 of the padded signal; frame t contributes j = P - hop t - left
     std::vector<float>& dst = gen[it % 3];
     for (int p = 0; p < L; ++p) {
-      const int q = p + g.n_fft / 2 - 15 * g.h;
+      const int q = p + g.n_fft / 2 - g.left;
       int tlo = q - (g.win - 1) <= 0 ? 0 : (q - (g.win - 1) + g.hop - 1) / g.hop;
       int thi = q / g.hop;
       if (thi > T - 1) thi = T - 1;
@@ -223,6 +226,7 @@ extern "C" int emu_fam_griffinlim(int n_fft, int hop, int T, int n_iter, float m
                                   const float* win, float* out) {
   FamGeom g;
   if (!fam_make_geom(n_fft, n_fft / 4, hop, &g)) return -1;
+  if (g.nrad == 20) return g.h == 441 ? gl_run<21, 21, 20>(g, T, n_iter, momentum, mag, ang, win, out) : -1;
   switch (g.h) {
     case 80: return gl_run<10, 8>(g, T, n_iter, momentum, mag, ang, win, out);
     case 160: return gl_run<16, 10>(g, T, n_iter, momentum, mag, ang, win, out);

@@ -1,7 +1,8 @@
 """
 CPU checks of the ROW-FAMILY frame transform shared by the gfx950 kernels of rfx_fam.hip (csrc/rfx_fam_core.h): geometries
 with n_fft = 40 h, win_length = 10 h - the reference's default 400 / 100 ms (spectrogram_params.py:24-27, :62-81) at 48, 32,
-24, 16 and 8 kHz, plus 44.1 kHz as a cross-check of the specialised engine's factorisation.  The header is compiled for the
+24, 16 and 8 kHz, plus 44.1 kHz as a cross-check of the specialised engine's factorisation - and, since round 4, n_fft = 20 h,
+win_length = 5 h with h = 441: 22.05 kHz, where the window (2205 samples) is not ten hops and sits at an odd offset (3307).  The header is compiled for the
 host with tests/emu/rfx_fam_emu.cpp, which loops the logical threads phase by phase, and compared with numpy's real FFT.
 """
 import ctypes
@@ -23,20 +24,20 @@ def emu(tmp_path_factory):
     return ctypes.CDLL(so)
 
 
-RATES = [48000, 32000, 24000, 16000, 8000, 44100]
+RATES = [48000, 32000, 24000, 16000, 8000, 44100, 22050]
 
 
 @pytest.mark.parametrize("rate", RATES)
 @pytest.mark.parametrize("rs_pad", [0, 7])
 def test_forward_and_inverse_match_numpy(emu, rate, rs_pad):
     n_fft, win = int(0.4 * rate), int(0.1 * rate)
-    h = n_fft // 40
+    left = (n_fft - win) // 2  # where torch.stft centres the window in the frame: 15 h in the 40 h family, 3307 at 22.05 kHz
     rng = np.random.default_rng(rate)
     u = rng.standard_normal(win).astype(np.float32)
     out = np.zeros(2 * (n_fft // 2 + 1), np.float32)
     assert emu.emu_fam_transform(n_fft, 0, rs_pad, u.ctypes.data_as(FP), out.ctypes.data_as(FP)) == 0
     frame = np.zeros(n_fft)
-    frame[15 * h:25 * h] = u
+    frame[left:left + win] = u
     ref = np.fft.rfft(frame)
     err = np.abs(out.view(np.complex64) - ref).max() / np.abs(ref).max()
     assert err < 2e-6, err
@@ -45,7 +46,7 @@ def test_forward_and_inverse_match_numpy(emu, rate, rs_pad):
     X = (rng.standard_normal(n_fft // 2 + 1) + 1j * rng.standard_normal(n_fft // 2 + 1)).astype(np.complex64)
     back = np.zeros(win, np.float32)
     assert emu.emu_fam_transform(n_fft, 1, rs_pad, X.view(np.float32).ctypes.data_as(FP), back.ctypes.data_as(FP)) == 0
-    want = np.fft.irfft(X.astype(np.complex128), n_fft)[15 * h:25 * h]
+    want = np.fft.irfft(X.astype(np.complex128), n_fft)[left:left + win]
     assert np.abs(back - want).max() / np.abs(want).max() < 2e-6
 
 
@@ -63,13 +64,14 @@ def test_geometries_outside_the_family_are_refused(emu):
     out = (ctypes.c_int * 6)()
     assert emu.emu_fam_geom(19200, 4800, 480, out) == 0 and list(out)[:4] == [480, 24, 20, 512]
     assert emu.emu_fam_geom(19200, 4800, 123, out) == 0          # the hop is free (frames are overlap-added afterwards)
-    assert emu.emu_fam_geom(8820, 2205, 220, out) == -1          # 22.05 kHz: win is not a multiple of ten
+    assert emu.emu_fam_geom(8820, 2205, 220, out) == 0 and list(out)[:4] == [441, 21, 21, 448]  # 22.05 kHz: the 20 h family (round 4)
+    assert emu.emu_fam_geom(4410, 1102, 110, out) == -1          # 11.025 kHz: neither 40 h nor 20 h
     assert emu.emu_fam_geom(19200, 4000, 480, out) == -1         # window not a quarter of the frame
     assert emu.emu_fam_geom(38400, 9600, 960, out) == -1         # 96 kHz: the 21 x 960 cube exceeds the LDS of a CU
     assert emu.emu_fam_geom(3465, 866, 86, out) == -1
 
 
-@pytest.mark.parametrize("rate,hop_ms,T,n_iter", [(8000, 10, 31, 0), (8000, 10, 31, 3), (16000, 5, 45, 2)])
+@pytest.mark.parametrize("rate,hop_ms,T,n_iter", [(8000, 10, 31, 0), (8000, 10, 31, 3), (16000, 5, 45, 2), (22050, 10, 33, 0), (22050, 10, 33, 2)])
 def test_griffinlim_on_the_emulated_kernels_matches_the_oracle(emu, rate, hop_ms, T, n_iter):
     """The whole loop as rfx_fam.hip + gen_fold_kernel run it (initial synthesis from S * angles0, analysis of
     x_k - m x_{k-1}, per-slot projection incl. the conjugate and duplicate slots, pruned synthesis, overlap-add and envelope
@@ -82,7 +84,7 @@ def test_griffinlim_on_the_emulated_kernels_matches_the_oracle(emu, rate, hop_ms
     import riffusion_oracle as O
 
     op = O.OracleParams(sample_rate=rate, step_size_ms=hop_ms, max_frequency=rate // 2)
-    assert op.n_fft == 40 * (op.n_fft // 40) and op.win_length * 4 == op.n_fft
+    assert op.n_fft % 20 == 0 and op.win_length * 4 == op.n_fft
     g = torch.Generator().manual_seed(rate + n_iter)
     mag = torch.rand(1, op.n_stft, T, generator=g) * 1000
     a0 = torch.rand(1, op.n_stft, T, dtype=torch.complex64, generator=g)

@@ -14,7 +14,7 @@ from helpers import snr_db, synthetic_tiles_u8, synthetic_wave
 
 pytestmark = pytest.mark.gpu
 
-RATES = [48000, 22050, 16000]
+RATES = [48000, 22050, 16000, 11025]  # 11.025 kHz (4410 / 1102 / 110) is in neither row family: generic FFT engine
 
 
 @pytest.fixture(scope="module")
@@ -178,9 +178,10 @@ def _plan_generic_only(p):
     return _hip.get_plan(p, "cuda", frame_engine="generic")
 
 
-@pytest.mark.parametrize("rate", [48000, 32000, 24000, 16000, 8000])
+@pytest.mark.parametrize("rate", [48000, 32000, 24000, 22050, 16000, 8000])
 def test_row_family_griffinlim_matches_oracle_and_generic_engine(O, rate):
-    """Griffin-Lim of the 40 h / 10 h geometries (the default 400 / 100 ms at these rates) runs on the row-family kernels
+    """Griffin-Lim of the 40 h / 10 h geometries (the default 400 / 100 ms at these rates) and of 22.05 kHz (20 h / 5 h with
+    h = 441, round 4: window offset 3307, cube columns rotated by 220) runs on the row-family kernels
     (csrc/rfx_fam.hip); rfx_plan_options.frame_engine = generic keeps it on the generic FFT engine.  Both against the oracle
     with injected initial angles, and against each other; the production RNG stream is the same on both."""
     p = _params(sample_rate=rate, max_frequency=min(10000, rate // 2))
@@ -236,7 +237,8 @@ def test_row_family_hop_is_free_and_other_windows_stay_generic(O):
     print(f"48 kHz, hop 240: row-family griffinlim n_iter=4: {s:.1f} dB")
     assert s >= 93.0
     assert _plan(_params(sample_rate=48000, window_duration_ms=50)).griffinlim_engine == "generic"
-    assert _plan(_params(sample_rate=22050)).griffinlim_engine == "generic"
+    assert _plan(_params(sample_rate=22050)).griffinlim_engine == "row-family"  # n_fft = 20 h, win = 5 h, h = 441 (round 4)
+    assert _plan(_params(sample_rate=11025)).griffinlim_engine == "generic"
     assert _plan(_params()).griffinlim_engine == "specialised"
 
 
