@@ -26,8 +26,9 @@ Extra objects on the JSON line:
                  divided by the launch duration measured with HIP events on the launch stream.
   cpu_baseline - the CPU oracle (oracle/riffusion_oracle.py, a torch-CPU port of the reference's
                  torchaudio path) timed on this host on ONE tile of the same workload.
-  other_sample_rates - the same decode step at 48 kHz (n_fft 19200 / win 4800 / hop 480: Griffin-Lim on the
-                 row-family kernels of csrc/rfx_fam.hip), measured after the timed region; context only.
+  other_sample_rates - the same decode step, and the forward path, at 48 kHz (n_fft 19200 / win 4800 / hop 480) and
+                 22.05 kHz (8820 / 2205 / 220): the row-family kernels of csrc/rfx_fam.hip, measured after the
+                 timed region; context only.
 """
 import argparse
 import ctypes
@@ -654,7 +655,7 @@ def main():
     other = None
     if rank == 0 and world == 1 and not args.no_other_rates:
         other = {}
-        for rate in (48000,):
+        for rate in (48000, 22050):
             p2 = SpectrogramParams(sample_rate=rate, num_griffin_lim_iters=args.iters)
             plan2 = _hip.get_plan(p2, dev)
 
@@ -677,7 +678,20 @@ def main():
             plan2.griffinlim(lin2, B, T, args.iters, 0.99, seed=3)
             e2[1].record()
             torch.cuda.synchronize(dev)
+            # forward path at this rate: B waveforms of T frames -> mel amplitudes -> uint8 images
+            wave2 = torch.randn(B, p2.hop_length * (T - 1), device=dev) * 8000
+            thr2 = torch.from_numpy(image_util.encode_thresholds(0.25)).to(dev)
+            for _ in range(2):
+                plan2.image_encode(plan2.mel_from_waveform(wave2), False, thr2)
+            e3 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e3[0].record()
+            for _ in range(5):
+                plan2.image_encode(plan2.mel_from_waveform(wave2), False, thr2)
+            e3[1].record()
+            torch.cuda.synchronize(dev)
+            fwd_ms = e3[0].elapsed_time(e3[1]) / 5
             other[str(rate)] = {"tiles_per_s": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3), "steps": n2,
+                                "forward_images_per_s": round(B / fwd_ms * 1e3, 0), "forward_ms": round(fwd_ms, 3),
                                 "griffinlim_ms": round(e2[0].elapsed_time(e2[1]), 3), "griffinlim_engine": plan2.griffinlim_engine,
                                 "n_fft": p2.n_fft, "hop_length": p2.hop_length, "finite": bool(torch.isfinite(pcm2.float()).all()),
                                 "workload": f"batch={B} synthetic 512x512 mono uint8 tiles -> audio at {rate} Hz, Griffin-Lim {args.iters}"}

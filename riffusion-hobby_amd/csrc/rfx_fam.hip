@@ -15,8 +15,18 @@
 // iteration, same buffers and same random stream as the generic engine, which remains the fallback for every other geometry.
 // |S| arrives in the plan's plain bin-ordered layout and is re-ordered ONCE per call into slot order (thread t's slot s at
 // s * nthr + t: every wave-wide load is whole lines); duplicate slots get the same magnitude.
+// This file is compiled TWICE (round 4).  Translation unit 0 (rfx_fam.hip itself, plain fp32 butterflies): the forward kernels,
+// the 48 kHz Griffin-Lim kernel, the launchers.  Translation unit 1 (rfx_fam_pk.hip: `#define RFX_PK 1`, `#define RFX_FAM_TU 1`,
+// then this file): the Griffin-Lim kernels of every other geometry with PACKED butterflies (rfx_core.h).  Measured, Griffin-Lim 32
+// of 64 tiles, packed against plain: 32 kHz 30.3 / 33.0 ms, 24 kHz 22.4 / 22.9, 22.05 kHz 20.7 / 22.2, 16 kHz 16.4 / 17.2,
+// 8 kHz 8.2 / 9.1 - no scratch left in those kernels - but 48 kHz 57.8 / 48.9 (the radix-24 pass spills 100 B with the packed
+// complex product's aligned pairs) and the forward kernels spill more everywhere.  The kernel templates carry the unit's number so
+// that the two instantiations of one geometry are different symbols.  (-DRFX_FAM_PK: packed in unit 0 as well, A/B runs.)
+#ifndef RFX_FAM_TU
+#define RFX_FAM_TU 0
+#endif
 #if defined(RFX_FAM_PK) && !defined(RFX_PK)
-#define RFX_PK 1  // A/B switch: packed fp32 butterflies in the row-family kernels (rfx_core.h)
+#define RFX_PK 1
 #endif
 #include <hip/hip_runtime.h>
 
@@ -52,14 +62,18 @@ constexpr int fam_threads(int ra, int rb, int nr = 40) {
 #define RFX_FAM_STREAM_AUX kAuxNT  // |S| is read once per iteration: streamed past L2
 #endif
 
+#if RFX_FAM_TU == 0
 bool fam_row_stride_even(const FamGeom& g) { return RFX_FAM_VEC && g.rb % 2 == 0; }
 size_t fam_lds_bytes(const FamGeom& g) { return sizeof(cf) * (size_t)g.rows * g.rs; }
+#endif
 
 // Where the pass-A twiddles W_h^{i p} live: in LDS (a static array next to the cube: the compiler then knows that cube stores
 // never alias twiddle reads) wherever two workgroups still share a CU with it - every geometry but 48 kHz, whose cube leaves
 // 1.2 KB - and in the L1-resident global table otherwise.
 constexpr bool fam_twiddles_in_lds(int ra, int rb) { return ra * rb != 480; }
+#if RFX_FAM_TU == 0
 size_t fam_static_lds_bytes(const FamGeom& g) { return fam_twiddles_in_lds(g.ra, g.rb) ? sizeof(cf) * (size_t)g.rb * (g.ra - 1) : 0; }
+#endif
 
 // the thread's RA - 1 pass-A twiddles, fetched in two batches
 template <int RA, bool LDS>
@@ -89,7 +103,7 @@ struct FamTwA {
 //   frame's P1 use the same values), and the next frame's ten input samples
 // Phases are fenced for the compiler's scheduler (left alone it hoists the next phase's loads over the current butterfly and
 // spills 70 registers).
-template <int MODE, int RA, int RB, int NR = 40>
+template <int MODE, int RA, int RB, int NR = 40, int TU = RFX_FAM_TU>
 __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu_waves_per_eu(4))) fam_gl_kernel(FamGlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* cube = reinterpret_cast<cf*>(smem);
@@ -270,6 +284,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
 #endif
 }
 
+#if RFX_FAM_TU == 0
 // ---- forward: Spectrogram(power=None) [+ abs] of the family geometries (spectrogram_converter.py:47-59, :179-182).  Same P1 /
 // A / B as above; the frame then changes places through LDS - once every row has been read the cube's memory becomes the
 // bin-ordered frame, each bin written by its primary slot (the direct one where a bin has two) - and leaves in whole lines, in
@@ -422,12 +437,16 @@ __global__ void __launch_bounds__(512) fam_repack_kernel(const float* __restrict
   }
 }
 
+#endif  // RFX_FAM_TU == 0
+
 using FamGlFn = void (*)(FamGlArgs);
 template <int RA, int RB, int NR = 40>
 static FamGlFn fam_fn(int mode) {
   return mode == 0 ? fam_gl_kernel<0, RA, RB, NR> : mode == 1 ? fam_gl_kernel<1, RA, RB, NR> : fam_gl_kernel<2, RA, RB, NR>;
 }
-static FamGlFn fam_fn(const FamGeom& g, int mode) {
+#if RFX_FAM_TU == 1
+// unit 1: the packed Griffin-Lim kernels (every geometry but 48 kHz)
+FamGlFn fam_gl_fn_packed(const FamGeom& g, int mode) {
   if (g.nrad == 20) return g.h == 441 ? fam_fn<21, 21, 20>(mode) : nullptr;  // 22.05 kHz
   switch (g.h) {
     case 80: return fam_fn<10, 8>(mode);
@@ -435,6 +454,25 @@ static FamGlFn fam_fn(const FamGeom& g, int mode) {
     case 240: return fam_fn<16, 15>(mode);
     case 320: return fam_fn<20, 16>(mode);
     case 441: return fam_fn<21, 21>(mode);
+    default: return nullptr;
+  }
+}
+#else
+FamGlFn fam_gl_fn_packed(const FamGeom& g, int mode);  // rfx_fam_pk.hip
+static FamGlFn fam_fn(const FamGeom& g, int mode) {
+#if !defined(RFX_NO_PK) && !defined(RFX_FAM_PK)
+  if (g.h != 480) return fam_gl_fn_packed(g, mode);
+#else
+  if (g.nrad == 20) return g.h == 441 ? fam_fn<21, 21, 20>(mode) : nullptr;  // 22.05 kHz
+#endif
+  switch (g.h) {
+#if defined(RFX_NO_PK) || defined(RFX_FAM_PK)
+    case 80: return fam_fn<10, 8>(mode);
+    case 160: return fam_fn<16, 10>(mode);
+    case 240: return fam_fn<16, 15>(mode);
+    case 320: return fam_fn<20, 16>(mode);
+    case 441: return fam_fn<21, 21>(mode);
+#endif
     case 480: return fam_fn<24, 20>(mode);
     default: return nullptr;
   }
@@ -493,5 +531,7 @@ hipError_t launch_fam_repack(const float* plain, float* slots, const int* bin_of
   hipLaunchKernelGGL(fam_repack_kernel, dim3((unsigned)nframes), dim3(512), sizeof(float) * (size_t)n_stft, stream, plain, slots, bin_of, fs_plain, fsf, n_stft);
   return hipGetLastError();
 }
+
+#endif  // RFX_FAM_TU
 
 }  // namespace rfx
