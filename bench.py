@@ -127,6 +127,47 @@ def pmc_summary():
         return {}
 
 
+def isa_mix(kernel_prefix: str):
+    """Committed instruction mix of a kernel's frame loop (tools/isa_mix.py -> profiles/isa_mix_latest.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_mix_latest.json")) as f:
+            d = json.load(f)
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel_prefix):
+                return dict(v, git=d.get("git", "not recorded"))
+    except Exception:
+        pass
+    return {}
+
+
+def valu_binding(valu_instr_per_launch: float, launch_ms: float, mix: dict, pmc: dict, pmc_src: str, rev: str):
+    """
+    The roofline that bounds the transform kernels since round 4: occupancy of the SIMDs' fp32 pipes.  A wave64 fp32
+    instruction holds its SIMD-32's pipe for 2 cycles, a packed one (v_pk_*_f32, two results per lane) for 4, a quarter-rate
+    transcendental for 8 (MI355X_MICROARCH.md), so pipe cycles per launch = VALU wave-instructions per launch (PMC
+    SQ_INSTS_VALU) x the average pipe cycles per VALU instruction of the kernel's frame loop (tools/isa_mix.py), against
+    1024 SIMDs x 2.4 GHz.  `frac_at_measured_clock` uses the clock the chip really ran the profiled launches at
+    (GRBM_GUI_ACTIVE / 8 XCDs / launch time of the PMC run: it clocks down to its power budget under this load).
+    (Rounds 1-3 priced wave-instructions per second against the issue rate: after packing, a third of the issue slots are gone
+    at unchanged pipe time - the kernel was never bound by issue)
+    """
+    cpi = mix.get("pipe_cycles_per_valu_instruction")
+    if not (valu_instr_per_launch and cpi):
+        return None
+    cycles = valu_instr_per_launch * cpi
+    got = cycles / (launch_ms * 1e-3) / 1e9
+    peak = 1024 * 2.4
+    out = {"bound": "valu_pipe", "unit": "G SIMD-cycles/s", "valu_wave_instructions_per_launch": valu_instr_per_launch,
+           "pipe_cycles_per_valu_instruction": cpi, "valu_pipe_cycles_per_launch": cycles, "achieved": round(got, 1), "peak": round(peak, 1),
+           "frac": round(got / peak, 4), "loop_mix": mix.get("loop_mix"), "source": pmc_src, "git": rev, "isa_mix_git": mix.get("git")}
+    gui, busy_ms = pmc.get("GRBM_GUI_ACTIVE_per_launch"), pmc.get("profiled_launch_ms")
+    if gui and busy_ms:
+        clk = gui / 8.0 / (busy_ms * 1e-3) / 1e9
+        out["measured_clock_ghz"] = round(clk, 3)
+        out["frac_at_measured_clock"] = round(got / (1024 * clk), 4)
+    return out
+
+
 def cpu_baseline(iters: int, threads_cap: int = 16, min_seconds: float = 10.0, max_tiles: int = 8):
     """
     The oracle (a torch-CPU port of the reference's torchaudio path) on the host cores, on a BOUNDED
@@ -294,15 +335,13 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
                 "note": "fused framed transform -> |X| -> banded mel projection in one launch: the mel GEMM of the reference (4.6 of its "
                         "4.94 GFLOP per tile) multiplies a banded filterbank (7 976 non-zeros of 4.5 M) and is evaluated as such on chip, so "
                         "neither HBM nor the MFMA pipes bound this kernel: `frac` (HBM) is small by construction, true_flops_frac prices the "
-                        "flops actually executed against the 157.3 TFLOP/s fp32 peak, and `binding` (VALU issue) is the resource that bounds it; "
+                        "flops actually executed against the 157.3 TFLOP/s fp32 peak, and `binding` (occupancy of the fp32 VALU pipes) is the resource that bounds it; "
                         "avg_launch_ms is one launch between two stream drains (HIP events)"}
         valu = fpmc.get("SQ_INSTS_VALU_per_launch")
         if valu:
-            valu *= fscale
-            got = valu / (mel_ms * 1e-3) / 1e9
-            roof["binding"] = {"bound": "valu", "unit": "G wave-instructions/s", "wave_instructions_per_launch": valu, "achieved": round(got, 1),
-                               "peak": 1228.8, "frac": round(got / 1228.8, 4), "sustained_peak": round(1024 / 1.13, 1),
-                               "frac_of_sustained": round(got / (1024 / 1.13), 4), "source": pmc_src, "git": profile_rev(fpmc, pmc_src)}
+            b = valu_binding(valu * fscale, mel_ms, isa_mix("rfx::stft_mel2_kernel"), fpmc, pmc_src, profile_rev(fpmc, pmc_src))
+            if b:
+                roof["binding"] = b
         k_exec = executed_mel_k()
         out = {
             "metric": "spectrogram_images_per_sec_forward",
@@ -564,12 +603,12 @@ def main():
                                   "launch stream: consecutive launches cannot overlap their tails there, so iterations x avg_launch_ms exceeds stages.griffinlim_ms slightly",
             # counters cannot be collected from inside the timed process: these fields are read from the committed
             # rocprofv3 --pmc summary of the same kernel (re-collected whenever the kernel changes)
-            "from_profiles": {"fields": ["traffic", "actual_hbm_gbs", "actual_hbm_frac", "binding.wave_instructions_per_launch"],
+            "from_profiles": {"fields": ["traffic", "actual_hbm_gbs", "actual_hbm_frac", "binding.valu_wave_instructions_per_launch", "binding.measured_clock_ghz"],
                               "source": pmc_src, "git": profile_rev(pmc, pmc_src)},
             # `achieved` prices the kernel against the CANONICAL fused formulation of SURVEY 8(d) (|S| 4 B + tprev
             # 8 B read + 8 B written per bin and iteration: an HBM-bound kernel).  The shipped kernel applies the
             # momentum in the time domain (STFT linearity), streams only |S| (`traffic` is what it really moves)
-            # and is bound by fp32 VALU issue: `binding` is the roofline that tracks progress from here.
+            # and is bound by the fp32 VALU pipes: `binding` is the roofline that tracks progress from here.
             "formulation": "time-domain momentum: rebuilt - m*tprev = STFT(x_k - m*x_{k-1}); 4 B/bin/iteration streamed",
         }
         if traffic:
@@ -578,15 +617,9 @@ def main():
         valu = pmc.get("SQ_INSTS_VALU_per_launch")
         valu = valu * pmc_scale if valu else valu
         if valu:
-            # spec issue rate (MI355X_MICROARCH.md): 1024 SIMD-32 units, a wave64 fp32 instruction every 2 cycles at 2.4 GHz
-            spec_ginstr = 1024 * 2.4 / 2
-            # sustained rate measured by tools/ubench/valu.hip (independent v_fma_f32, 8 waves per SIMD: the chip clocks
-            # down under full VALU load): 1.13 ns per wave-instruction per SIMD
-            sustained_ginstr = 1024 / 1.13
-            got = valu / (avg_ms * 1e-3) / 1e9
-            roofline["binding"] = {"bound": "valu", "unit": "G wave-instructions/s", "wave_instructions_per_launch": valu,
-                                   "achieved": round(got, 1), "peak": round(spec_ginstr, 1), "frac": round(got / spec_ginstr, 4),
-                                   "sustained_peak": round(sustained_ginstr, 1), "frac_of_sustained": round(got / sustained_ginstr, 4)}
+            b = valu_binding(valu, avg_ms, isa_mix("rfx::gl_iter_kernel<2>"), pmc, pmc_src, profile_rev(pmc, pmc_src))
+            if b:
+                roofline["binding"] = b
         # stage split of one step (events through torch on the current stream = the launch stream)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         evs[0].record()

@@ -244,7 +244,6 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     if (gg.nc > kGenMaxNc)
       return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: n_fft = " + std::to_string(params->n_fft) + ": the frame's FFT buffer (" +
                   std::to_string(gg.nc) + " complex numbers) does not fit the 160 KiB of LDS of a CU");
-    gg.nthr = 512;
     if (!gen_factor(gg.nc, gg.radix, &gg.nstages))
       return fail(RFX_ERR_UNSUPPORTED, "rfx_plan_create: FFT length " + std::to_string(gg.nc) + " (from n_fft = " + std::to_string(params->n_fft) +
                   ") has a prime factor above 13; implemented radices: 2, 3, 4, 5, 7, 11, 13");

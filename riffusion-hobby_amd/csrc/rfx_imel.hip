@@ -218,8 +218,9 @@ RFX_HD size_t imel_group_lds_bytes(int M, int max_iter) { return sizeof(float) *
 //    one (torchaudio's melscale_fbanks, norm=None; checked to 1e-6 per bin at plan creation), so the gradient
 //    d0 w0 + d1 w1 = d1 + (d0 - d1) w0: one FMA per bin less, and momentum folds into the first (`fma(mom, buf, d1)`).
 //    The sums A and B keep both weights (a thread's unused register slots carry w0 = w1 = 0 and must stay out of them; their
-//    spec values drift inside [0, 1] and touch nothing).  Emulated on the CPU against the oracle the two forms sit at the
-//    same distance (rel-L2 2.1e-7 both).
+//    spec values drift inside [0, 1] and touch nothing).  Unlike the power-of-two scaling above this is NOT bit-identical to
+//    the two-weight form: the weights sum to one only to 1e-6 and the gradient is rounded differently; emulated on the CPU
+//    against the oracle the two forms sit at the same distance (rel-L2 2.1e-7 both).
 constexpr float kImelScale = 8.673617379884035e-19f;    // 2^-60
 constexpr float kImelUnscale = 1152921504606846976.0f;  // 2^60
 #ifndef RFX_IMEL_CLAMP

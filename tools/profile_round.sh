@@ -45,6 +45,12 @@ for key, fname in (("gl_iter_kernel<2>", "gl_iter_pmc.json"), ("stft_mel2_kernel
                        "each counter group collected in its own rocprofv3 --kernel-trace --pmc run of bench.py"}
         for c in names[2:]:
             if k in tables[c]: res[c + "_per_launch"] = tables[c][k][1]
+        # launch duration inside the counter runs (the chip clocks differently under the profiler): from their kernel traces
+        durs = []
+        for f in glob.glob(out + "/pmc_GRBM_GUI_ACTIVE/*kernel_trace.csv"):
+            for r in csv.DictReader(open(f)):
+                if key in r.get("Kernel_Name", ""): durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        if durs: res["profiled_launch_ms"] = sum(durs) / len(durs)
     json.dump(res, open(out + "/" + fname, "w"), indent=1)
     print(fname, json.dumps(res)[:600])
 PY
