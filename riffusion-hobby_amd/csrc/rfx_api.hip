@@ -888,12 +888,15 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     fa.L = L;
     const long long nframes = (long long)B * T, slots = (long long)plan->num_cus * plan->fam_wgs_per_cu;
     const int nblocks = (int)(nframes < slots ? nframes : slots);
+    // x_it lives in gen[it % 2]; gen[2] holds d_it = x_it - m x_{it-1} (d_0 = x_0), which the fold writes next to x_it and the
+    // next launch analyses (the kernel used to form it from two generations itself)
     for (int it = 0; it <= n_iter; ++it) {
-      fa.x_cur = gen[(it + 2) % 3];
-      fa.x_prev = gen[(it + 1) % 3];
-      RFX_HIP(launch_fam_gl(it == 0 ? 0 : it == 1 ? 1 : 2, fa, nblocks, stream));
+      fa.x_cur = gen[2];
+      fa.x_prev = nullptr;
+      RFX_HIP(launch_fam_gl(it == 0 ? 0 : 1, fa, nblocks, stream));
       const bool last = it == n_iter;
-      RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+      RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 2], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream,
+                              it == 0 ? nullptr : gen[(it + 1) % 2], last ? nullptr : gen[2], fa.mom));
       if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
     }
     if (h_launch_ms) {

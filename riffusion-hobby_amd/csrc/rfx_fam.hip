@@ -96,7 +96,8 @@ struct FamTwA {
   }
 };
 
-// MODE 0: Z = S * angles0 (injected or drawn) -> synthesis; MODE 1: analysis of x_0; MODE 2: analysis of x_k - m x_{k-1}
+// MODE 0: Z = S * angles0 (injected or drawn) -> synthesis; MODE 1 / 2: analysis of d = x_k - m x_{k-1} (x_0 in the first iteration;
+// the two modes are the same code since the fold forms d)
 // 128 VGPRs: two 512-thread workgroups per CU at 48 kHz.  Every table / HBM value is requested one barrier before its use:
 //   before P1 | A : first half of the pass-A twiddles            before A | B : the frame's |S|
 //   before B' | A': first half of the conjugate twiddles          before A'| P1': g(n')^k1 and the Hann samples (P1' and the NEXT
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
   wa.tab = twa_lds + iA * (RA - 1);
   // g(n')^k1 for k1 = 1..10 and 20 only (fam_g_pow)
   cf w1[12];
-  float wv[WH], u[WH], pv[WH];
+  float wv[WH], u[WH];
   auto load_tables = [&] {
 #pragma unroll
     for (int k = 1; k <= (NR == 40 ? 11 : 10); ++k) {
@@ -154,21 +155,17 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
   auto g1 = [&w1](int k) { return fam_g_pow(w1, k); };
   // frame fr is centred on sample hop * fr of the reflect-padded estimate (torch.stft center=True): the window covers
   // positions hop * fr + off .. hop * fr + off + win - 1, off = left - n_fft / 2 (-5 h in the 40 h family)
+  // (x_cur holds d = x_k - m x_{k-1} since round 4: the fold of the previous iteration forms it, one load per window sample
+  // here instead of two and ten registers less across P1')
   auto load_samples = [&](long long gf) {
     const int clip = (int)(gf / a.T), fr = (int)(gf - (long long)clip * a.T);
     const rsrc_t xc = make_rsrc(a.x_cur + (size_t)clip * a.audio_stride, (size_t)a.L * sizeof(float));
-    const rsrc_t xp = make_rsrc(a.x_prev + (size_t)clip * a.audio_stride, (size_t)a.L * sizeof(float));
 #pragma unroll
-    for (int j = 0; j < WH; ++j) {
-      const unsigned p4 = (unsigned)reflect_index(a.g.hop * fr + a.g.off + j * H + npr, a.L) * 4u;
-      u[j] = ld1(xc, p4, 0);
-      if (MODE == 2) pv[j] = ld1(xp, p4, 0);
-    }
+    for (int j = 0; j < WH; ++j) u[j] = ld1(xc, (unsigned)reflect_index(a.g.hop * fr + a.g.off + j * H + npr, a.L) * 4u, 0);
   };
-  // u = (x_k - m x_{k-1}) * window, formed as soon as the samples are in (ten registers across P1' instead of twenty)
   auto window_samples = [&] {
 #pragma unroll
-    for (int j = 0; j < WH; ++j) u[j] = (MODE == 2 ? fmaf(-a.mom, pv[j], u[j]) : u[j]) * wv[j];
+    for (int j = 0; j < WH; ++j) u[j] *= wv[j];
   };
   if (MODE != 0 && (long long)blockIdx.x < nframes) {
     load_tables();

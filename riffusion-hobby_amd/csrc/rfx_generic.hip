@@ -324,8 +324,13 @@ __global__ void __launch_bounds__(256) gen_env_kernel(const float* __restrict__ 
   }
   env[p] = e;
 }
+// Optional second output (row-family Griffin-Lim, round 4): the signal the NEXT iteration analyses, d = x_{k+1} - m x_k (x_k =
+// `prev`; d = x_{k+1} when prev is null: the first iteration has no momentum term).  The Griffin-Lim kernel then fetches one
+// value per window sample instead of two and needs ten registers less across its last phase; the fold has x_{k+1} in a register
+// anyway.  Same fma as the kernel used to do: same bits.
 __global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__ frames, const float* __restrict__ env,
-                                                       float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride) {
+                                                       float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride,
+                                                       const float* __restrict__ prev, float* __restrict__ dout, float mom) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (p >= L) return;
@@ -334,10 +339,13 @@ __global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__
   gen_fold_range(g, q, T, tlo, thi);
   float acc = 0.f;
   for (int t = tlo; t <= thi; ++t) acc += frames[((size_t)b * T + t) * g.win + (q - g.hop * t)];
-  out[(size_t)b * out_stride + p] = acc / env[p];
+  const float x = acc / env[p];
+  out[(size_t)b * out_stride + p] = x;
+  if (dout) dout[(size_t)b * out_stride + p] = prev ? fmaf(-mom, prev[(size_t)b * out_stride + p], x) : x;
 }
 __global__ void __launch_bounds__(256) gen_fold4_kernel(const float* __restrict__ frames, const float* __restrict__ env,
-                                                        float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride) {
+                                                        float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride,
+                                                        const float* __restrict__ prev, float* __restrict__ dout, float mom) {
   using v4 = float __attribute__((ext_vector_type(4)));
   const int p = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
   const int b = blockIdx.y;
@@ -348,7 +356,16 @@ __global__ void __launch_bounds__(256) gen_fold4_kernel(const float* __restrict_
   v4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int t = tlo; t <= thi; ++t) acc += *reinterpret_cast<const v4*>(frames + ((size_t)b * T + t) * g.win + (q - g.hop * t));
   const v4 e = *reinterpret_cast<const v4*>(env + p);
-  *reinterpret_cast<v4*>(out + (size_t)b * out_stride + p) = v4{acc.x / e.x, acc.y / e.y, acc.z / e.z, acc.w / e.w};
+  const v4 x = v4{acc.x / e.x, acc.y / e.y, acc.z / e.z, acc.w / e.w};
+  *reinterpret_cast<v4*>(out + (size_t)b * out_stride + p) = x;
+  if (dout) {
+    v4 d = x;
+    if (prev) {
+      const v4 xp = *reinterpret_cast<const v4*>(prev + (size_t)b * out_stride + p);
+      d = v4{fmaf(-mom, xp.x, x.x), fmaf(-mom, xp.y, x.y), fmaf(-mom, xp.z, x.z), fmaf(-mom, xp.w, x.w)};
+    }
+    *reinterpret_cast<v4*>(dout + (size_t)b * out_stride + p) = d;
+  }
 }
 
 // ---- (B, F, T) <-> [B*T][fs] layout conversion (tiled transposes; the padding of the frame stride is zeroed)
@@ -476,11 +493,12 @@ hipError_t launch_gen_env(const float* win, float* env, const GenGeom& g, int T,
   return hipGetLastError();
 }
 hipError_t launch_gen_fold(const float* frames, const float* env, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
-                           hipStream_t stream) {
+                           hipStream_t stream, const float* prev, float* dout, float mom) {
   const bool vec = g.win % 4 == 0 && g.hop % 4 == 0 && (g.n_fft / 2 - g.left) % 4 == 0 && L % 4 == 0 && out_stride % 4 == 0 &&
-                   (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(env) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(gen_fold4_kernel, dim3((L / 4 + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride);
-  else hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride);
+                   (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(env) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(prev) & 15) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(gen_fold4_kernel, dim3((L / 4 + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride, prev, dout, mom);
+  else hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride, prev, dout, mom);
   return hipGetLastError();
 }
 

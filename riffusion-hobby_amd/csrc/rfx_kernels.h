@@ -181,8 +181,9 @@ struct GenGlArgs {
   GenTables tb;
   const float* S;        // [B*T][fs] magnitudes
   const cf* angles0;     // mode 0: optional injected initial angles [B*T][fs] (drawn from `seed` when null)
-  const float* x_cur;    // modes 1, 2: x_k      [B][audio_stride], L valid samples per clip
-  const float* x_prev;   // mode 2:     x_{k-1}
+  const float* x_cur;    // modes 1, 2: the signal to analyse, d = x_k - m x_{k-1} (x_0 in the first iteration), formed by the fold of
+                         // the previous iteration (launch_gen_fold's `dout`): [B][audio_stride], L valid samples per clip
+  const float* x_prev;   // unused since round 4 (the kernel used to form d itself from x_k and x_{k-1})
   size_t audio_stride;
   float* frames;         // [B*T][win] windowed, scaled synthesis frames (gen_fold_kernel overlap-adds them)
   float mom;             // momentum / (1 + momentum)
@@ -195,7 +196,7 @@ hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStrea
 hipError_t launch_gen_gl(int mode, const GenGlArgs& a, int num_cus, hipStream_t stream);      // mode 0 init, 1 first iteration, 2 iteration
 hipError_t launch_gen_env(const float* win, float* env, const GenGeom& g, int T, int L, hipStream_t stream);  // env[p] = sum_t w[j]^2, once per call
 hipError_t launch_gen_fold(const float* frames, const float* env, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
-                           hipStream_t stream);  // L output samples per clip
+                           hipStream_t stream, const float* prev = nullptr, float* dout = nullptr, float mom = 0.f);  // L output samples per clip
 hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_mel(const float* mag, float* mel_tm, const float* band_wt, const int* band_lo, const int* band_len, long long nframes,
