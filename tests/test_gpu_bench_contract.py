@@ -35,13 +35,17 @@ def test_headline_line_small_batch():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["binding"]["bound"] == "valu" and 0 < r["binding"]["frac"] < 1.2 and "source" in r["from_profiles"]
+    b = r["binding"]  # round 4: occupancy of the fp32 pipes (PMC instruction count x pipe cycles per instruction of the ISA mix)
+    assert b["bound"] == "valu_pipe" and 0 < b["frac"] < 1.0 and b["frac"] <= b.get("frac_at_measured_clock", 1.0) and "source" in r["from_profiles"]
+    assert b["loop_mix"]["valu_packed"] > b["loop_mix"]["valu_plain"] > 0 and 2.0 <= b["pipe_cycles_per_valu_instruction"] <= 4.0
     f = d["forward"]
     assert f["unit"] == "images/s" and f["value"] > 0 and f["roofline"]["kernel"] == "rfx::stft_mel2_kernel" and 0 < f["roofline"]["true_flops_frac"] < 1
     assert {"image_decode_ms", "inverse_mel_ms", "griffinlim_ms", "pcm16_ms"} <= set(d["stages"])
     assert 0 < d["single_tile_latency"]["mono_ms"] < d["single_tile_latency"]["stereo_ms"] * 1.5
     o = d["other_sample_rates"]["48000"]
     assert o["griffinlim_engine"] == "row-family" and o["n_fft"] == 19200 and o["tiles_per_s"] > 0 and o["finite"] is True
+    o2 = d["other_sample_rates"]["22050"]
+    assert o2["griffinlim_engine"] == "row-family" and o2["n_fft"] == 8820 and o2["tiles_per_s"] > 0 and o2["forward_images_per_s"] > 0
 
 
 def test_distributed_launch_one_rank_keeps_stdout_clean():
@@ -60,4 +64,10 @@ def test_sharded_stereo_workload_small():
                         "--warmup", "0"], capture_output=True, text=True, timeout=600)
     d = _one_json_line(p)
     assert d["scaling"] == "strong" and d["config"]["griffin_lim_iters"] == 64 and d["config"]["global_batch"] == 4 and d["value"] > 0
-    assert d["config"]["gather"] == "none" and {"compute_ms", "compute_plus_d2h_ms", "d2h_exposed_ms", "d2h_own_shard_raw_ms"} <= set(d["stages"])
+    assert d["config"]["gather"] == "none" and {"compute_ms", "compute_plus_d2h_ms", "d2h_exposed_ms", "d2h_own_shard_raw_ms",
+                                                 "host_in_host_out_ms", "h2d_exposed_ms"} <= set(d["stages"])
+    # the same workload with the tiles in host memory when the timed region starts (the reference's API: host in, host out)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "decode-stereo64", "--global-clips", "4", "--steps", "1",
+                        "--warmup", "0", "--host-input"], capture_output=True, text=True, timeout=600)
+    d = _one_json_line(p)
+    assert "HOST memory" in d["config"]["workload"] and d["value"] > 0
