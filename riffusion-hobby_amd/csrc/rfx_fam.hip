@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
 #endif
   }
 #ifdef RFX_FAM_TIMING
-  if (MODE == 2 && (blockIdx.x == 7 || blockIdx.x == 300) && (threadIdx.x == 0 || threadIdx.x == 256 || threadIdx.x == 448))
+  if (MODE == 1 && (blockIdx.x == 7 || blockIdx.x == 300) && (threadIdx.x == 0 || threadIdx.x == 256 || threadIdx.x == 448))
     printf("fam_gl timing, block %d of %d, thread %d (100 MHz ticks per frame, %d frames): P1 %.1f | barriers %.1f | A %.1f | B+proj+B' %.1f | A' %.1f | P1' %.1f | loop top %.1f\n",
            (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, nfr, (double)tacc[1] / nfr, (double)tacc[2] / nfr, (double)tacc[3] / nfr, (double)tacc[4] / nfr, (double)tacc[5] / nfr,
            (double)tacc[6] / nfr, (double)tacc[0] / nfr);
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(512) fam_repack_kernel(const float* __restrict
 using FamGlFn = void (*)(FamGlArgs);
 template <int RA, int RB, int NR = 40>
 static FamGlFn fam_fn(int mode) {
-  return mode == 0 ? fam_gl_kernel<0, RA, RB, NR> : mode == 1 ? fam_gl_kernel<1, RA, RB, NR> : fam_gl_kernel<2, RA, RB, NR>;
+  return mode == 0 ? fam_gl_kernel<0, RA, RB, NR> : fam_gl_kernel<1, RA, RB, NR>;  // (modes 1 and 2 are one kernel since the fold forms d)
 }
 #if RFX_FAM_TU == 1
 // unit 1: the packed Griffin-Lim kernels (every geometry but 48 kHz)
@@ -503,7 +503,7 @@ hipError_t prepare_fam_kernels(const FamGeom& g) {
     const hipError_t e = hipFuncSetAttribute((const void*)fam_fwd_fn(g, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam_lds_bytes(g));
     if (e != hipSuccess) return e;
   }
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 2; ++mode) {
     const FamGlFn fn = fam_fn(g, mode);
     if (!fn) return hipErrorInvalidValue;
     const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam_lds_bytes(g));
@@ -514,7 +514,7 @@ hipError_t prepare_fam_kernels(const FamGeom& g) {
 
 int fam_blocks_per_cu(const FamGeom& g) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)fam_fn(g, 2), g.nthr, fam_lds_bytes(g)) != hipSuccess || n < 1) n = 1;  // (counts the static LDS too)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)fam_fn(g, 1), g.nthr, fam_lds_bytes(g)) != hipSuccess || n < 1) n = 1;  // (counts the static LDS too)
   return n;
 }
 

@@ -148,9 +148,10 @@ def test_silent_inputs_do_what_numpy_does(O):
 
 
 def test_og_beat_mean_spectral_convergence_32_fresh_seeds(O, golden_dir):
-    """configs[0] with production RNG on both sides, 32 draws per side.  The oracle's 32 values are a committed table (pure CPU,
-    deterministic per seed); the device draws 32 NEW initialisations on every run (seed from the clock, printed), so a generator
-    whose statistics were off would show as a shifted mean run after run.  Gate: 1 % on the means."""
+    """configs[0] with production RNG on both sides: 32 oracle draws, 64 device draws.  The oracle's 32 values are a committed table
+    (pure CPU, deterministic per seed); the device draws 64 NEW initialisations on every run (seed from the clock, printed), so a
+    generator whose statistics were off would show as a shifted mean run after run.  Gate: 1 % on the means; the
+    means have sigma 0.17 % (oracle, 32) and 0.18 % (device, 64), the device sat +0.4 % above the table in four sessions."""
     from riffusion.spectrogram_params import SpectrogramParams
     from riffusion.util import image_util
 
@@ -163,7 +164,7 @@ def test_og_beat_mean_spectral_convergence_32_fresh_seeds(O, golden_dir):
     with Image.open(os.path.join(golden_dir, "og_beat.png")) as im:
         rgb = np.asarray(image_util.rgb_array_from_image(im))
     mel = torch.from_numpy(O.spectrogram_from_image_u8(rgb, 0.25, False, 30e6))
-    n = 32
+    n = 64  # twice the oracle's count: the device's fresh draws are the cheap side, and the gate should not flake on them
     seed = int(time.time() * 1000) & 0x7FFFFFFF
     mel_n = mel.cuda().repeat(n, 1, 1).contiguous()
     lin_slots = plan.inverse_mel(mel_n, 1, seed=seed)
@@ -171,7 +172,7 @@ def test_og_beat_mean_spectral_convergence_32_fresh_seeds(O, golden_dir):
     lin_d = plan.unpack_magnitudes(lin_slots, n, T_FULL).cpu()
     sc_d = [O.spectral_convergence(waves[s : s + 1], lin_d[s : s + 1], op) for s in range(n)]
     md, sd = float(np.mean(sc_d)), float(np.std(sc_d))
-    print(f"og_beat spectral convergence, 32 seeds per side (device seed {seed}): oracle mean {mo:.5f} (std {so:.5f}), device mean {md:.5f} "
+    print(f"og_beat spectral convergence, 32 oracle / {n} device seeds (device seed {seed}): oracle mean {mo:.5f} (std {so:.5f}), device mean {md:.5f} "
           f"(std {sd:.5f}), relative difference of the means {(md - mo) / mo:+.4f}")
     assert abs(md - mo) <= 0.01 * mo
     assert len({round(x, 6) for x in sc_d}) == n
