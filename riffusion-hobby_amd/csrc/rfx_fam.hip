@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
       // increasing bin order like gen_mel_kernel
       for (int m = tid; m < a.Mpad; m += NT) {
         float acc = 0.f;
+#ifndef RFX_ABL_FAM_NOMEL  // (ablation: what the sum phase costs)
         if (m < a.M) {
           const int lo = a.band_lo[m], n = a.band_len[m];
           const float* __restrict__ wcol = a.band_wt + m;
@@ -403,6 +404,9 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
             for (int e = 0; e < 8; ++e) acc = fmaf(w[e], v[e], acc);
           }
         }
+#else
+        acc = magl[m];
+#endif
         a.mel_tm[(size_t)gf * a.Mpad + m] = acc;
       }
     } else if (MODE == 1) {

@@ -23,3 +23,7 @@ for i, n in enumerate(names):
     tot += us
     print(f"{n:28s} {us:7.2f} us/frame   (min wave {t[:,:,i].min().item()/frames/100:.2f}, max {t[:,:,i].max().item()/frames/100:.2f})")
 print("sum", round(tot, 2), "us per WG-frame")
+# per-workgroup totals: how far apart do the workgroups of one launch finish?  (the tail a launch boundary exposes)
+tot_wg = t[:, :, :10].sum(dim=2).max(dim=1).values / 100.0 / 6.0   # us per launch (6 iterations ran; modes 1 + 2: 6 launches with timers)
+print(f"per-workgroup time per launch: mean {tot_wg.mean().item():.1f} us, min {tot_wg.min().item():.1f}, max {tot_wg.max().item():.1f} "
+      f"-> the slowest workgroup is {100 * (tot_wg.max().item() / tot_wg.mean().item() - 1):.1f} % behind the mean")
