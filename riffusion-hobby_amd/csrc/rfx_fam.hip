@@ -372,11 +372,12 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
         const int k = k0 + NR * RA * s;
         const bool cj = k > a.g.n_fft / 2;
         const int bin = cj ? a.g.n_fft - k : k;
-        if (fam_slot_is_primary(NR, rowB, cj)) {  // rows 0 and 20 hold their bins twice: the direct slot writes
-          if (MODE == 1) cube[bin] = cf{R[s].re, cj ? -R[s].im : R[s].im};
-          // v_sqrt_f32 (1 ulp) instead of the IEEE expansion: |X| carries ~1e-7 relative error from the transform anyway
-          else magl[bin] = __builtin_amdgcn_sqrtf(fmaf(R[s].re, R[s].re, R[s].im * R[s].im));
-        }
+        // rows 0 and nrad / 2 hold their bins twice: the direct slot writes, the other one stores into a dump entry past the
+        // frame (a select instead of a branch per slot: twenty s_and_saveexec / s_cbranch pairs per frame in round 3)
+        const int at = fam_slot_is_primary(NR, rowB, cj) ? bin : n_stft + (tid & 31);
+        if (MODE == 1) cube[at] = cf{R[s].re, cj ? -R[s].im : R[s].im};
+        // v_sqrt_f32 (1 ulp) instead of the IEEE expansion: |X| carries ~1e-7 relative error from the transform anyway
+        else magl[at] = __builtin_amdgcn_sqrtf(fmaf(R[s].re, R[s].re, R[s].im * R[s].im));
       }
     }
     RFX_SCHED_FENCE();
