@@ -918,13 +918,16 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   a.T = T;
   a.L = L;
   for (int it = 0; it <= n_iter; ++it) {
-    // iteration `it` analyses x_{it-1} - m * x_{it-2} (the momentum term of the reference's `rebuilt - m * tprev`, applied in
-    // the time domain) and writes the frames of x_it; it == 0 synthesises the initial estimate from S * angles0
-    a.x_cur = gen[(it + 2) % 3];
-    a.x_prev = gen[(it + 1) % 3];
-    RFX_HIP(launch_gen_gl(it == 0 ? 0 : it == 1 ? 1 : 2, a, plan->num_cus, stream));
+    // iteration `it` analyses d = x_{it-1} - m * x_{it-2} (the momentum term of the reference's `rebuilt - m * tprev`, applied in
+    // the time domain; d = x_0 for it == 1) and writes the frames of x_it; it == 0 synthesises the initial estimate from
+    // S * angles0.  As on the row family, the fold of iteration it - 1 forms d next to x_{it-1} (x_it lives in gen[it % 2], d in
+    // gen[2]), so the kernel runs its one-signal mode for every iteration: half the audio loads, same bits.
+    a.x_cur = gen[2];
+    a.x_prev = nullptr;
+    RFX_HIP(launch_gen_gl(it == 0 ? 0 : 1, a, plan->num_cus, stream));
     const bool last = it == n_iter;
-    RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 3], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+    RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 2], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream,
+                            it == 0 ? nullptr : gen[(it + 1) % 2], last ? nullptr : gen[2], a.mom));
     if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
   }
   if (h_launch_ms) {

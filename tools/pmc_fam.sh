@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / HBM counters of the row-family Griffin-Lim kernel at 48 kHz (fam_gl_kernel<2, 24, 20>, 64 tiles per launch): separate
+# SQ / HBM counters of the row-family Griffin-Lim kernel at 48 kHz (fam_gl_kernel<1, 24, 20, 40, 0>: the iterating mode, 64 tiles per launch): separate
 # --pmc passes with --kernel-trace only, every rocprofv3 run under its own timeout.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_fam; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 kernel = ""
 for f in sorted(glob.glob("$OUT/p*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "fam_gl_kernel<2" not in r.get("Kernel_Name", ""): continue
+        if "fam_gl_kernel<1" not in r.get("Kernel_Name", ""): continue
         kernel = r["Kernel_Name"]
         a = agg[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 res = {"kernel": kernel, "batch_tiles": 64, "frames_per_tile": 512, "sample_rate": 48000,
