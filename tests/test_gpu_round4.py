@@ -175,7 +175,7 @@ def test_og_beat_mean_spectral_convergence_32_fresh_seeds(O, golden_dir):
     print(f"og_beat spectral convergence, 32 oracle / {n} device seeds (device seed {seed}): oracle mean {mo:.5f} (std {so:.5f}), device mean {md:.5f} "
           f"(std {sd:.5f}), relative difference of the means {(md - mo) / mo:+.4f}")
     assert abs(md - mo) <= 0.01 * mo
-    assert len({round(x, 6) for x in sc_d}) == n
+    assert len(set(sc_d)) == n  # n different draws, not one repeated (exact floats: rounded to six digits, 64 values collide by chance)
 
 
 def test_fused_forward_with_more_than_512_filters(O):
