@@ -99,18 +99,29 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   // analysis input d = x_k - m*x_{k-1} of thread n' for hop blocks fr-5 .. fr+4: a register sliding
   // window like `acc` (the reflect-padded signal is a fixed function of the padded position, so the
   // value a frame needs for block beta is the one its predecessor loaded): 4 loads per frame, not 40
-  auto load_d = [&](int blk) {
+  // The next frame's new sample is REQUESTED before the synthesis barrier and COMBINED after it (at the top of the next trip):
+  // with the sum formed where the loads are issued, hipcc put it - and an `s_waitcnt vmcnt(0)` for all 35 requests of the phase,
+  // twiddles and window included - in front of the barrier (seen in the ISA, round 4), which is not what "in flight across the
+  // barrier" means.  (Measured on one box: 24.5-25.1 ms with the wait, 24.6-25.0 without - the requests had landed by then.)
+  struct DRaw { float a0, a1, p0, p1; };
+  auto request_d = [&](int blk) {
     const unsigned p4 = (unsigned)reflect_index(blk * kHop + t.npr, g.L) * 4u;
-    float x = ld1(in0, p4, 0) + ld1(in1, p4, 0);
-    if (MODE == 2) x = fmaf(-g.mom, ld1(pv0, p4, 0) + ld1(pv1, p4, 0), x);
+    DRaw r{ld1(in0, p4, 0), ld1(in1, p4, 0), 0.f, 0.f};
+    if (MODE == 2) { r.p0 = ld1(pv0, p4, 0); r.p1 = ld1(pv1, p4, 0); }
+    return r;
+  };
+  auto combine_d = [&](const DRaw& r) {
+    float x = r.a0 + r.a1;
+    if (MODE == 2) x = fmaf(-g.mom, r.p0 + r.p1, x);
     return x;
   };
+  auto load_d = [&](int blk) { return combine_d(request_d(blk)); };
   float d[10];
-  float d_next = 0.f;
+  DRaw d_next{0.f, 0.f, 0.f, 0.f};
   if (MODE != 0) {
 #pragma unroll
     for (int j = 1; j < 10; ++j) d[j] = load_d(t0 + j - 1 - kHalfHops);  // blocks of frame t0-1 shifted in below
-    d_next = load_d(t0 + 9 - kHalfHops);
+    d_next = request_d(t0 + 9 - kHalfHops);
   }
   (void)d_next;
 
@@ -164,7 +175,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #pragma unroll
       for (int j = 0; j < 9; ++j) d[j] = d[j + 1];
 #ifdef RFX_PREFETCH_D
-      d[9] = d_next;
+      d[9] = combine_d(d_next);
 #else
       d[9] = load_d(fr + 9 - kHalfHops);
 #endif
@@ -237,7 +248,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
                   [&] {
                     RFX_STAMP(4);
                     load_window();
-                    if (MODE != 0) d_next = load_d(fr + 10 - kHalfHops);
+                    if (MODE != 0) d_next = request_d(fr + 10 - kHalfHops);
                     pend_scale = scale_of(fr - kHalfHops);
                   },
                   [&] { RFX_STAMP(5); }, [&](int i) { RFX_STAMP(8 + i); });
