@@ -238,6 +238,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     gg.even = params->n_fft % 2 == 0;
     gg.nc = gg.even ? params->n_fft / 2 : params->n_fft;
     gg.left = (params->n_fft - params->win_length) / 2;
+    gen_frame_layout(gg);
     gg.fs = (gg.n_stft + 63) / 64 * 64;
     gg.nhi = gg.nc / kGenTwLo + 1;
     gg.nhi2 = gg.nc / kGenTwLo + 2;
@@ -837,7 +838,7 @@ static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames
   Lpad = (int)align_up((size_t)gen_out_len(g, T), 64);
   size_t o = 0;
   off_frames = o;
-  o += align_up(nf * g.win * sizeof(float), 256);
+  o += align_up(nf * g.fpitch * sizeof(float), 256);
   off_audio = o;
   o += align_up((3 * (size_t)B + 1) * Lpad * sizeof(float), 256);  // + the window envelope of the fold, [Lpad]
   if (plan->fam_ok) o += align_up(nf * plan->fam.fsf * sizeof(float), 256);
@@ -862,6 +863,8 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   for (int i = 0; i < 3; ++i) gen[i] = (float*)(ws + oa) + (size_t)i * B * Lpad;  // x_k lives in gen[k % 3]
   float* env = (float*)(ws + oa) + (size_t)3 * B * Lpad;
   RFX_HIP(launch_gen_env(plan->d_win, env, g, T, L, stream));
+  // padded frame rows (gen_frame_layout): the kernels write the window samples only, the fold reads the padding as zeros
+  if (g.fshift > 0) RFX_HIP(hipMemsetAsync(frames, 0, (size_t)B * T * g.fpitch * sizeof(float), stream));
   EventList events;
   if (h_launch_ms) {
     RFX_HIP(events.create(n_iter + 2));
@@ -878,6 +881,8 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     fa.fs_plain = g.fs;
     fa.audio_stride = (size_t)Lpad;
     fa.frames = frames;
+    fa.fpitch = g.fpitch;
+    fa.fshift = g.fshift;
     fa.tw1 = plan->d_fam_tw;
     fa.twa = plan->d_fam_tw + (size_t)f.rows * f.h;
     fa.win = plan->d_win;

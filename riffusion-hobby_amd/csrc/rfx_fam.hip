@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
       float y[WH];
       fam_p1_load_inverse<NR>(cube, g1, y, col, rs);
       if (act1) {
-        const rsrc_t out = make_rsrc(a.frames + (size_t)gf * a.g.win, (size_t)WH * H * sizeof(float));
+        const rsrc_t out = make_rsrc(a.frames + (size_t)gf * a.fpitch + a.fshift, (size_t)WH * H * sizeof(float));
 #pragma unroll
         for (int j = 0; j < WH; ++j) st1<RFX_FAM_STORE_AUX>(y[j] * (wv[j] * oscale), out, npr4, (unsigned)j * (H * 4u));
       }

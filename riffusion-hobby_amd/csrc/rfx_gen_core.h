@@ -54,7 +54,24 @@ struct GenGeom {
   int radix[kGenMaxStages];
   int nthr;     // threads per workgroup the kernels are launched with (gen_pick_threads)
   int pad_shift;  // LDS padding of the in-place buffer (gen_ipad), 0 = none
+  // synthesis-frame buffer [B*T][fpitch]: window sample j of a frame sits at fshift + j.  Plain (fpitch = win, fshift = 0) unless
+  // gen_frame_layout found a shift that lets the fold read 16 bytes at a time (hop a multiple of four but the window length or its
+  // offset in the padded signal not: 22.05 kHz, 2205 / 1103): then the row is padded with >= 3 zeros on either side
+  int fpitch, fshift;
 };
+// Frame-buffer layout for the overlap-add (gen_fold4_kernel): output sample p reads frame t at j = p + n_fft / 2 - left - hop t.  Four
+// consecutive p (p % 4 == 0) read 16 aligned bytes from every frame iff hop % 4 == 0 and (n_fft / 2 - left + fshift) % 4 == 0 and
+// fpitch % 4 == 0; where the window's ends fall inside such a group the neighbours must read zeros: three floats of padding
+RFX_HD void gen_frame_layout(GenGeom& g) {
+  const int off = g.n_fft / 2 - g.left;
+  g.fshift = 0;
+  g.fpitch = g.win;
+  if (g.hop % 4 != 0 || (g.win % 4 == 0 && off % 4 == 0)) return;
+  int sh = (4 - off % 4) % 4;
+  while (sh < 3) sh += 4;
+  g.fshift = sh;
+  g.fpitch = (sh + g.win + 3 + 3) / 4 * 4;
+}
 
 // radices the butterfly below implements
 RFX_HD bool gen_factor(int n, int* radix, int* nstages) {

@@ -266,7 +266,7 @@ gen_gl_kernel(GenGlArgs a) {
     GSTAMP(3);
     const cf* z = gen_fft<true, MAXR>(g, l, a.tb.tw);  // starts with a barrier
     GSTAMP(4);
-    float* __restrict__ out = a.frames + (size_t)fr * g.win;
+    float* __restrict__ out = a.frames + (size_t)fr * g.fpitch + g.fshift;
     {
       constexpr int UO = 5;  // window samples fetched per batch before the stores
       const int nthr = (int)blockDim.x;
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__
   int tlo, thi;
   gen_fold_range(g, q, T, tlo, thi);
   float acc = 0.f;
-  for (int t = tlo; t <= thi; ++t) acc += frames[((size_t)b * T + t) * g.win + (q - g.hop * t)];
+  for (int t = tlo; t <= thi; ++t) acc += frames[((size_t)b * T + t) * g.fpitch + g.fshift + (q - g.hop * t)];
   const float x = acc / env[p];
   out[(size_t)b * out_stride + p] = x;
   if (dout) dout[(size_t)b * out_stride + p] = prev ? fmaf(-mom, prev[(size_t)b * out_stride + p], x) : x;
@@ -350,11 +350,16 @@ __global__ void __launch_bounds__(256) gen_fold4_kernel(const float* __restrict_
   const int p = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
   const int b = blockIdx.y;
   if (p >= L) return;
-  const int q = p + g.n_fft / 2 - g.left;  // a multiple of four, like hop: q .. q + 3 share their frame range
-  int tlo, thi;
-  gen_fold_range(g, q, T, tlo, thi);
+  // q + fshift is a multiple of four, like hop and fpitch: every frame is read 16 aligned bytes at a time.  Plain layout: q .. q + 3
+  // share their frame range.  Padded layout (gen_frame_layout): the window's ends may fall inside the group - the frames of q's
+  // first and (q + 3)'s last are all read, and a sample outside a frame's window reads the zero padding of its row (x + 0 = x:
+  // the same sums as the scalar fold, term for term)
+  const int q = p + g.n_fft / 2 - g.left;
+  int tlo, thi, tmp;
+  gen_fold_range(g, q, T, tlo, tmp);
+  gen_fold_range(g, q + 3, T, tmp, thi);
   v4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int t = tlo; t <= thi; ++t) acc += *reinterpret_cast<const v4*>(frames + ((size_t)b * T + t) * g.win + (q - g.hop * t));
+  for (int t = tlo; t <= thi; ++t) acc += *reinterpret_cast<const v4*>(frames + ((size_t)b * T + t) * g.fpitch + g.fshift + (q - g.hop * t));
   const v4 e = *reinterpret_cast<const v4*>(env + p);
   const v4 x = v4{acc.x / e.x, acc.y / e.y, acc.z / e.z, acc.w / e.w};
   *reinterpret_cast<v4*>(out + (size_t)b * out_stride + p) = x;
@@ -494,7 +499,7 @@ hipError_t launch_gen_env(const float* win, float* env, const GenGeom& g, int T,
 }
 hipError_t launch_gen_fold(const float* frames, const float* env, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
                            hipStream_t stream, const float* prev, float* dout, float mom) {
-  const bool vec = g.win % 4 == 0 && g.hop % 4 == 0 && (g.n_fft / 2 - g.left) % 4 == 0 && L % 4 == 0 && out_stride % 4 == 0 &&
+  const bool vec = g.fpitch % 4 == 0 && g.hop % 4 == 0 && (g.n_fft / 2 - g.left + g.fshift) % 4 == 0 && L % 4 == 0 && out_stride % 4 == 0 &&
                    (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(env) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(prev) & 15) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0;
   if (vec) hipLaunchKernelGGL(gen_fold4_kernel, dim3((L / 4 + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride, prev, dout, mom);

@@ -212,7 +212,8 @@ struct FamGlArgs {
   const float* x_cur;    // modes 1, 2: x_k      [B][audio_stride], L valid samples per clip
   const float* x_prev;   // mode 2:     x_{k-1}
   size_t audio_stride;
-  float* frames;         // [B*T][win] windowed, scaled synthesis frames
+  float* frames;         // [B*T][fpitch] windowed, scaled synthesis frames, window sample j at fshift + j (GenGeom::fpitch / fshift)
+  int fpitch, fshift;
   const cf* tw1;         // [21][h]      g(n')^k1
   const cf* twa;         // [rb][ra-1]   W_h^{i p}
   const float* win;      // [win]
