@@ -175,7 +175,9 @@ def test_og_beat_mean_spectral_convergence_32_fresh_seeds(O, golden_dir):
     print(f"og_beat spectral convergence, 32 oracle / {n} device seeds (device seed {seed}): oracle mean {mo:.5f} (std {so:.5f}), device mean {md:.5f} "
           f"(std {sd:.5f}), relative difference of the means {(md - mo) / mo:+.4f}")
     assert abs(md - mo) <= 0.01 * mo
-    assert len(set(sc_d)) == n  # n different draws, not one repeated (exact floats: rounded to six digits, 64 values collide by chance)
+    # different draws, not one repeated.  (Not "== n": the figure is a float32 with ~5e5 equally likely values around its mean - two
+    # of 64 draws coincide in one run of 270, and did in this round's last visit; rounded to six digits they collide in one run of 4.)
+    assert len(set(sc_d)) >= n - 2
 
 
 def test_fused_forward_with_more_than_512_filters(O):
