@@ -178,6 +178,8 @@ def test_og_beat_mean_spectral_convergence_32_fresh_seeds(O, golden_dir):
     # different draws, not one repeated.  (Not "== n": the figure is a float32 with ~5e5 equally likely values around its mean - two
     # of 64 draws coincide in one run of 270, and did in this round's last visit; rounded to six digits they collide in one run of 4.)
     assert len(set(sc_d)) >= n - 2
+    # the exact form of the same property: no two clips share a waveform or a starting spectrogram
+    assert len({waves[s].numpy().tobytes() for s in range(n)}) == n and len({lin_d[s].numpy().tobytes() for s in range(n)}) == n
 
 
 def test_fused_forward_with_more_than_512_filters(O):
