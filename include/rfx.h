@@ -94,6 +94,12 @@ typedef enum {
                              transform (row family with h = 441, or the generic FFT engine with RFX_ENGINE_GENERIC) - cross-checks */
 } rfx_plan_layout;
 
+/* Which InverseMelScale kernel family a plan may select (rfx_plan_imel_kernel reports the choice) */
+typedef enum {
+  RFX_IMEL_FORM_AUTO = 0,   /* the wave kernel (one wave per frame) where the bank admits it, else the group kernels */
+  RFX_IMEL_FORM_GROUPS = 1  /* never the wave kernel: the group kernels (one workgroup of four waves per frame) - cross-checks */
+} rfx_imel_form;
+
 /* Plan-creation options.  Set struct_size = sizeof(rfx_plan_options); zero in every other field means "default".
  * This struct is the library's ONLY configuration surface: a release build reads no environment variable (the RFX_*
  * experiment switches of the source exist only in builds made with -DRFX_ABLATION, tools/build_variants.sh). */
@@ -104,6 +110,7 @@ typedef struct {
                                   workgroup slot of the chip (0 = default, 4: the measured crossover, 8 tiles per call) */
   int32_t frame_engine;        /* rfx_frame_engine */
   int32_t plan_layout;         /* rfx_plan_layout; added in round 4 - a caller built against the shorter struct gets AUTO */
+  int32_t imel_form;           /* rfx_imel_form; added in round 4 after plan_layout, same rule */
 } rfx_plan_options;
 
 /* rfx_plan_create with options (NULL = defaults = rfx_plan_create). */
@@ -179,7 +186,8 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
  * channels and frames).  d_spec0: optional injected start (B, T, n_stft) float32 in the reference's
  * own layout, NULL = U[0,1) from `seed`.  Output: linear magnitudes in slot layout, ready for
  * rfx_griffinlim. */
-/* which SGD kernel rfx_inverse_mel runs for this plan's filterbank: 2 = group kernel with per-wave register budgets sized to
+/* which SGD kernel rfx_inverse_mel runs for this plan's filterbank: 4 = wave kernel (one wave per frame, weights as a line per
+ * group: the default 512-filter HTK bank without normalisation, max_mel_iters <= 611), 2 = group kernel with per-wave register budgets sized to
  * the default 512-filter HTK bank (with or without slaney normalisation), 3 = the same kernel with the wider budget set
  * (mel_scale_type "slaney"), 1 = group kernel with a uniform budget (other banks whose groups fit 8 / 24 bins),
  * 0 = general LDS kernel (any banded bank), -1 = not banded (rfx_inverse_mel refuses) */

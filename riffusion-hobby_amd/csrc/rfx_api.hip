@@ -174,6 +174,7 @@ int rfx_plan_imel_kernel(const rfx_plan* plan) {
   if (!plan || !plan->d_melfb || !plan->imel_ok) return -1;
   if (plan->imel_variant == 2) return 0;
   if (plan->imel_variant == 1) return plan->imel.fast_ok == 1 || plan->imel.fast_ok == 2 ? 1 : 0;
+  if (plan->imel_variant == 0 && plan->imel.wave_ok) return 4;
   return plan->imel.fast_ok;
 }
 // torch.stft(center=True): the signal is reflect-padded by n_fft/2 on both sides, so a waveform of Lw samples gives
@@ -223,6 +224,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: frame_engine must be RFX_ENGINE_AUTO or RFX_ENGINE_GENERIC");
     if (opt.plan_layout < RFX_LAYOUT_AUTO || opt.plan_layout > RFX_LAYOUT_GENERIC)
       return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: plan_layout must be RFX_LAYOUT_AUTO or RFX_LAYOUT_GENERIC");
+    if (opt.imel_form < RFX_IMEL_FORM_AUTO || opt.imel_form > RFX_IMEL_FORM_GROUPS)
+      return fail(RFX_ERR_INVALID, "rfx_plan_create_ex: imel_form must be RFX_IMEL_FORM_AUTO or RFX_IMEL_FORM_GROUPS");
   }
   const bool generic = params->n_fft != kNfft || params->win_length != kWin || params->hop_length != kHop ||
                        opt.plan_layout == RFX_LAYOUT_GENERIC;
@@ -501,7 +504,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     std::vector<int> grp_start(M + 1, 0);
     bool fast = ok && M <= 512;
     int fast_code = 0;
-    bool unit_form = false;
+    bool unit_form = false, wave_ok = false;
+    std::vector<float> lin;
     if (fast) {
       int prev = 0;
       for (int f = f_lo; f < f_hi && fast; ++f) {
@@ -536,6 +540,31 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
           if (g2 < M - 256) continue;
           if (g2 == M - 1) unit_form = bin_w1[f] == 0.f;
           else unit_form = fabsf(bin_w0[f] + bin_w1[f] - 1.f) <= 1e-6f;
+        }
+        // wave kernel (rfx_imel.hip::imel_wave_kernel): 512 groups dealt to 64 lanes in eight chunks whose budgets must hold every
+        // group, weights linear in the bin index inside a group (least-squares line in double, checked per bin), unit form in the
+        // upper four chunks, and a step count its padding slots survive (buffer -1e37 decaying by the momentum 0.9 per step)
+        wave_ok = RFX_IMEL_WAVE && opt.imel_form == RFX_IMEL_FORM_AUTO && fast_code == 2 && unit_form && M == 64 * rfx::kImelWaveChunks &&
+                  (double)params->max_mel_iters * 0.045757490560675115 <= 28.0;
+        for (int c = 0; c < rfx::kImelWaveChunks && wave_ok; ++c)
+          for (int lane = 0; lane < 64; ++lane)
+            if (cnt[rfx::imel_wave_group(c, lane)] > 2 * rfx::kImelWavePairs[c]) wave_ok = false;
+        lin.assign(4 * (size_t)M, 0.f);
+        for (int g2 = 0; g2 < M && wave_ok; ++g2) {
+          const int n = cnt[g2], f0 = grp_start[g2];
+          if (n == 0) continue;
+          for (int which = 0; which < 2; ++which) {
+            const std::vector<float>& w = which ? bin_w1 : bin_w0;
+            double sx = 0, sy = 0, sxx = 0, sxy = 0;
+            for (int i = 0; i < n; ++i) { sx += i; sy += w[f0 + i]; sxx += (double)i * i; sxy += (double)i * w[f0 + i]; }
+            const double den = n * sxx - sx * sx;
+            const double slope = n > 1 ? (n * sxy - sx * sy) / den : 0.0, icpt = (sy - slope * sx) / n;
+            const float af = (float)icpt, sf = (float)slope;
+            for (int i = 0; i < n; ++i)
+              if (fabs((double)af + (double)sf * i - (double)w[f0 + i]) > 1e-6) wave_ok = false;
+            lin[(size_t)(2 * which) * M + g2] = af;
+            lin[(size_t)(2 * which + 1) * M + g2] = sf;
+          }
         }
       }
     }
@@ -653,7 +682,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
       const size_t o_w = take(nnz * 4), o_ptr = take((M + 1) * 4), o_lo = take(M * 4), o_m0 = take(F * 4),
                    o_w0 = take(F * 4), o_w1 = take(F * 4), o_p = take(F * 4), o_p2 = take(F * 4),
-                   o_gs = take((M + 1) * 4);
+                   o_gs = take((M + 1) * 4), o_lin = take(4 * (size_t)M * 4);
       std::vector<char> blob(off);
       memcpy(&blob[o_w], csr_w.data(), nnz * 4);
       memcpy(&blob[o_ptr], csr_ptr.data(), (M + 1) * 4);
@@ -664,6 +693,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       memcpy(&blob[o_p], bin_pos.data(), F * 4);
       memcpy(&blob[o_p2], bin_pos2.data(), F * 4);
       memcpy(&blob[o_gs], grp_start.data(), (M + 1) * 4);
+      if (fast && wave_ok) memcpy(&blob[o_lin], lin.data(), 4 * (size_t)M * 4);
       RFX_HIP(hipMalloc(&pl->d_imel_blob, off));
       RFX_HIP(hipMemcpy(pl->d_imel_blob, blob.data(), off, hipMemcpyHostToDevice));
       char* d = (char*)pl->d_imel_blob;
@@ -678,6 +708,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->imel.grp_start = (const int*)(d + o_gs);
       pl->imel.fast_ok = fast ? fast_code : 0;
       pl->imel.unit_form = fast && unit_form ? 1 : 0;
+      pl->imel.lin = (const float*)(d + o_lin);
+      pl->imel.wave_ok = fast && wave_ok ? 1 : 0;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;

@@ -117,6 +117,16 @@ constexpr int kImelHiCap[4] = {23, 16, 12, 9};
 // so its low groups are longer, and its top groups reach 26 bins)
 constexpr int kImelLoCapWide[4] = {5, 3, 5, 6};
 constexpr int kImelHiCapWide[4] = {26, 17, 12, 9};
+// Wave kernel (round 4, rfx_imel.hip::imel_wave_kernel): ONE wave per frame.  The 512 groups are dealt to the 64 lanes in eight
+// chunks of 64 consecutive groups, even chunks in lane order and odd chunks reversed (group 64 c + lane / 64 c + 63 - lane), so a
+// lane's bin count is within 4 % of the mean although group sizes grow 12-fold over the bank, and every group's neighbours sit
+// in the adjacent lane (a DPP wave shift) or, at the chunk seams, in the lane itself.  Budget per chunk in register PAIRS:
+constexpr int kImelWaveChunks = 8;
+constexpr int kImelWavePairs[kImelWaveChunks] = {2, 2, 3, 3, 5, 6, 8, 12};
+RFX_HD int imel_wave_group(int chunk, int lane) { return (chunk & 1) ? 64 * chunk + 63 - lane : 64 * chunk + lane; }
+#ifndef RFX_IMEL_WAVE
+#define RFX_IMEL_WAVE 1  // 0: build without selecting the wave kernel (A/B against the group kernels)
+#endif
 
 // banded InverseMelScale SGD (torchaudio 0.13 semantics), one workgroup per frame
 struct ImelTables {
@@ -135,6 +145,10 @@ struct ImelTables {
                          // 3: only the wide per-wave set fits
   int unit_form;         // 1: in every long group (the top 256) a bin's two weights sum to one (to 1e-6) - the last group, whose second
                          // filter does not exist, carries w1 == 0: the per-wave kernels compute the gradient as d1 + (d0 - d1) w0
+  const float* lin;      // [4][M] a0 | s0 | a1 | s1: within group g the weights are w0 = a0 + s0 i, w1 = a1 + s1 i for the group's i-th bin
+                         // (triangular filters on a uniform bin grid; fitted and checked to 1e-6 per bin at plan creation)
+  int wave_ok;           // 1: imel_wave_kernel serves this bank (M == 512, the chunk budgets fit, the weights are linear per group, unit
+                         // form holds, and max_mel_iters is within the range the padding trick of the kernel covers)
 };
 struct ImelArgs {
   ImelTables tb;

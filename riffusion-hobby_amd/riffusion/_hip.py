@@ -49,12 +49,13 @@ class RfxPlanOptions(ctypes.Structure):
     """rfx_plan_options of include/rfx.h."""
 
     _fields_ = [("struct_size", ctypes.c_uint32), ("gl_form", ctypes.c_int32), ("gl_frames_per_slot", ctypes.c_int32),
-                ("frame_engine", ctypes.c_int32), ("plan_layout", ctypes.c_int32)]
+                ("frame_engine", ctypes.c_int32), ("plan_layout", ctypes.c_int32), ("imel_form", ctypes.c_int32)]
 
 
 GL_FORMS = {"auto": 0, "runs": 1, "frames": 2}  # rfx_gl_form
 FRAME_ENGINES = {"auto": 0, "generic": 1}       # rfx_frame_engine
 PLAN_LAYOUTS = {"auto": 0, "generic": 1}        # rfx_plan_layout
+IMEL_FORMS = {"auto": 0, "groups": 1}           # rfx_imel_form
 GL_ENGINE_NAMES = {0: "specialised", 1: "generic", 2: "row-family"}  # rfx_plan_griffinlim_engine
 
 
@@ -209,7 +210,7 @@ class Plan:
     """Owns one rfx_plan (device constants for one parameter set on one device)."""
 
     def __init__(self, params: T.Any, device: torch.device, gl_form: str = "auto", frame_engine: str = "auto",
-                 plan_layout: str = "auto"):
+                 plan_layout: str = "auto", imel_form: str = "auto"):
         self.lib = load_library()
         if gl_form not in GL_FORMS:
             raise ValueError(f"gl_form must be one of {sorted(GL_FORMS)}, got {gl_form!r}")
@@ -217,6 +218,8 @@ class Plan:
             raise ValueError(f"frame_engine must be one of {sorted(FRAME_ENGINES)}, got {frame_engine!r}")
         if plan_layout not in PLAN_LAYOUTS:
             raise ValueError(f"plan_layout must be one of {sorted(PLAN_LAYOUTS)}, got {plan_layout!r}")
+        if imel_form not in IMEL_FORMS:
+            raise ValueError(f"imel_form must be one of {sorted(IMEL_FORMS)}, got {imel_form!r}")
         self.gl_form = gl_form
         self.device = device
         self.n_fft, self.win_length, self.hop_length = params.n_fft, params.win_length, params.hop_length
@@ -235,7 +238,8 @@ class Plan:
         cp = RfxParams(params.sample_rate, self.n_fft, self.win_length, self.hop_length, self.n_mels, params.max_mel_iters)
         handle = c_void_p()
         self.device = device = resolve_device(device)
-        opt = RfxPlanOptions(ctypes.sizeof(RfxPlanOptions), GL_FORMS[gl_form], 0, FRAME_ENGINES[frame_engine], PLAN_LAYOUTS[plan_layout])
+        opt = RfxPlanOptions(ctypes.sizeof(RfxPlanOptions), GL_FORMS[gl_form], 0, FRAME_ENGINES[frame_engine], PLAN_LAYOUTS[plan_layout],
+                             IMEL_FORMS[imel_form])
         check(
             self.lib.rfx_plan_create_ex(
                 ctypes.byref(cp), self.window.data_ptr(), self.melfb.data_ptr(), device.index, ctypes.byref(opt), ctypes.byref(handle)
@@ -499,12 +503,12 @@ class Plan:
 # 18 MB at the default parameters), and a server that builds its parameters from image EXIF (cli.py:77-87) would otherwise
 # grow the cache with every distinct parameter set for ever.  An evicted plan is destroyed when its last user lets go of it.
 PLAN_CACHE_SIZE = max(1, int(os.environ.get("RFX_PLAN_CACHE", "8")))
-_plans: "collections.OrderedDict[T.Tuple[T.Any, int, str, str, str], Plan]" = collections.OrderedDict()
+_plans: "collections.OrderedDict[T.Tuple[T.Any, int, str, str, str, str], Plan]" = collections.OrderedDict()
 _plans_lock = threading.Lock()
 
 
 def get_plan(params: T.Any, device: T.Union[str, torch.device], gl_form: str = "auto", frame_engine: str = "auto",
-             plan_layout: str = "auto") -> Plan:
+             plan_layout: str = "auto", imel_form: str = "auto") -> Plan:
     """Plans are immutable and cached per (frozen params, device, options), at most PLAN_CACHE_SIZE of them (least recently
     used evicted): constructing a converter per request, as the reference's server does (server.py:159), costs a
     dictionary lookup.
@@ -513,13 +517,15 @@ def get_plan(params: T.Any, device: T.Union[str, torch.device], gl_form: str = "
     shape), "runs" (always the run-based fused kernel) or "frames" (always the per-frame kernel + fold);
     `frame_engine` = "generic" keeps Griffin-Lim of the 40 h / 10 h geometries (48 kHz ...) on the generic FFT engine
     instead of the row-family kernels (rfx_plan_options.frame_engine; cross-checks); `plan_layout` = "generic" builds the
-    generic plan also for the default geometry (rfx_plan_options.plan_layout; cross-checks of the specialised engine)."""
+    generic plan also for the default geometry (rfx_plan_options.plan_layout; cross-checks of the specialised engine);
+    `imel_form` = "groups" keeps InverseMelScale on the group kernels where "auto" takes the wave kernel
+    (rfx_plan_options.imel_form; cross-checks)."""
     dev = resolve_device(device)  # 'cuda' is keyed by the GPU it means now, not bound for good to the first one used
-    key = (params, dev.index, gl_form, frame_engine, plan_layout)
+    key = (params, dev.index, gl_form, frame_engine, plan_layout, imel_form)
     with _plans_lock:
         plan = _plans.get(key)
         if plan is None:
-            plan = Plan(params, dev, gl_form, frame_engine, plan_layout)
+            plan = Plan(params, dev, gl_form, frame_engine, plan_layout, imel_form)
             _plans[key] = plan
             while len(_plans) > PLAN_CACHE_SIZE:
                 _plans.popitem(last=False)  # dropped from the cache; freed when the last converter holding it goes

@@ -48,8 +48,9 @@ def test_mono_tile_full_size_inverse_mel_and_griffinlim32(O):
     params = SpectrogramParams()
     op = O.params_from(params)
     plan = _plan(params)
-    # the SGD kernel this test pins is the one bench.py times: per-wave groups, clamp as an output modifier, unit-form gradient
-    assert plan.lib.rfx_plan_imel_kernel(plan.handle) == 2 and plan.lib.rfx_plan_imel_unit_form(plan.handle) == 1
+    # the SGD kernel this test pins is the one bench.py times: the wave kernel (one wave per frame, weights as a line per group),
+    # clamp as an output modifier, unit-form gradient in the upper chunks
+    assert plan.lib.rfx_plan_imel_kernel(plan.handle) == 4 and plan.lib.rfx_plan_imel_unit_form(plan.handle) == 1
     tile = synthetic_tiles_u8(1)[0]
     mel = torch.from_numpy(O.spectrogram_from_image_u8(tile, 0.25, False, 30e6))  # (1, 512, 512)
     lut = torch.from_numpy(image_util.decode_lut(0.25, 30e6)).cuda()

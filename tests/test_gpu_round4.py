@@ -273,3 +273,41 @@ def test_plan_cache_returns_device_memory():
     for i in range(cap + 1):
         _hip.get_plan(SpectrogramParams(max_mel_iters=300 + i), "cuda")
     assert held.handle and held.mel_from_waveform(synthetic_wave(1, 441 * 45).cuda()).shape == (1, 512, 46)
+
+
+def test_inverse_mel_wave_kernel_against_group_kernels_and_oracle(O):
+    """The two InverseMelScale kernel families on the default bank: the wave kernel (rfx_plan_imel_kernel 4: one wave per frame,
+    weights as a line per group, neighbours through DPP wave shifts) and the group kernels it replaced as the default
+    (rfx_plan_options.imel_form = GROUPS, kernel 2).  Same injected start: both within the gate of the oracle and much closer to
+    each other; same seed and no injected start: both draw the same initial values per (frame, bin), so they stay as close;
+    untouched bins and duplicate slots bit for bit; stereo clips couple through the loss scale only."""
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    params = SpectrogramParams()
+    op = O.params_from(params)
+    wave_plan, group_plan = _plan(params), _plan(params, imel_form="groups")
+    assert wave_plan.lib.rfx_plan_imel_kernel(wave_plan.handle) == 4 and group_plan.lib.rfx_plan_imel_kernel(group_plan.handle) == 2
+    act = O.mel_filterbank(op).abs().sum(1) > 0
+    for C, T in ((1, 40), (2, 24)):
+        g = torch.Generator().manual_seed(100 + C)
+        mel = (torch.rand(C, 512, T, generator=g) ** 3 * 2e7)
+        spec0 = torch.rand(C, T, op.n_stft, generator=g)
+        want = O.inverse_mel_scale_sgd(mel, op, spec0=spec0)
+        slots_w = wave_plan.inverse_mel(mel.cuda(), C, spec0=spec0.cuda())
+        got_w = wave_plan.unpack_magnitudes(slots_w, C, T).cpu()
+        got_g = group_plan.unpack_magnitudes(group_plan.inverse_mel(mel.cuda(), C, spec0=spec0.cuda()), C, T).cpu()
+        nrm = torch.linalg.norm(want[:, act])
+        rel_w, rel_g = float(torch.linalg.norm(got_w[:, act] - want[:, act]) / nrm), float(torch.linalg.norm(got_g[:, act] - want[:, act]) / nrm)
+        rel_wg = float(torch.linalg.norm(got_w[:, act] - got_g[:, act]) / nrm)
+        print(f"InverseMelScale C={C} T={T}: wave kernel vs oracle {rel_w:.2e}, group kernels vs oracle {rel_g:.2e}, wave vs group {rel_wg:.2e}")
+        assert rel_w <= 1e-3 and rel_g <= 1e-3 and rel_wg <= 1e-5
+        assert torch.equal(got_w[:, ~act], spec0.transpose(1, 2)[:, ~act])  # untouched bins: the injected start, bit for bit
+        assert torch.equal(wave_plan.pack_magnitudes(got_w.cuda()), slots_w)  # duplicate slots carry their primary's value
+        assert float(got_w.min()) >= 0.0 and bool(torch.isfinite(got_w).all())
+    # seeded start: the same (seed, frame, bin) stream in both kernels
+    mel = (torch.rand(3, 512, 16, generator=torch.Generator().manual_seed(9)) ** 3 * 2e7).cuda()
+    a = wave_plan.unpack_magnitudes(wave_plan.inverse_mel(mel, 1, seed=77), 3, 16)
+    b = group_plan.unpack_magnitudes(group_plan.inverse_mel(mel, 1, seed=77), 3, 16)
+    assert torch.equal(a[:, ~act.cuda()], b[:, ~act.cuda()])  # pass-through bins ARE the drawn values
+    assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) <= 1e-5
+    assert not torch.equal(a, wave_plan.unpack_magnitudes(wave_plan.inverse_mel(mel, 1, seed=78), 3, 16))

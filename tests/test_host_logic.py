@@ -436,16 +436,18 @@ def test_plan_options_are_validated_before_any_device_call(repo_root):
     from riffusion import _hip
     from riffusion.spectrogram_params import SpectrogramParams
 
-    assert [f[0] for f in _hip.RfxPlanOptions._fields_] == ["struct_size", "gl_form", "gl_frames_per_slot", "frame_engine", "plan_layout"]
-    assert ctypes.sizeof(_hip.RfxPlanOptions) == 20
+    assert [f[0] for f in _hip.RfxPlanOptions._fields_] == ["struct_size", "gl_form", "gl_frames_per_slot", "frame_engine", "plan_layout",
+                                                                "imel_form"]
+    assert ctypes.sizeof(_hip.RfxPlanOptions) == 24
     assert _hip.FRAME_ENGINES == {"auto": 0, "generic": 1} and _hip.GL_FORMS == {"auto": 0, "runs": 1, "frames": 2}
-    assert _hip.PLAN_LAYOUTS == {"auto": 0, "generic": 1}
+    assert _hip.PLAN_LAYOUTS == {"auto": 0, "generic": 1} and _hip.IMEL_FORMS == {"auto": 0, "groups": 1}
     header = open(os.path.join(repo_root, "include", "rfx.h")).read()
     assert "RFX_ENGINE_AUTO = 0" in header and "RFX_ENGINE_GENERIC = 1" in header and "int32_t frame_engine;" in header
     assert "RFX_LAYOUT_AUTO = 0" in header and "RFX_LAYOUT_GENERIC = 1" in header and "int32_t plan_layout;" in header
+    assert "RFX_IMEL_FORM_AUTO = 0" in header and "RFX_IMEL_FORM_GROUPS = 1" in header and "int32_t imel_form;" in header
     # the release library reads no environment variable: every getenv of the C++ side sits behind RFX_ABLATION / RFX_TIMING
     api = open(os.path.join(repo_root, "riffusion-hobby_amd", "csrc", "rfx_api.hip")).read()
     assert api.count("getenv(") == 2 and "#ifdef RFX_ABLATION\n  return getenv(name);" in api and 'getenv("RFX_TIMING_PTR")' in api
-    for kw in ({"gl_form": "sometimes"}, {"frame_engine": "fastest"}, {"plan_layout": "dense"}):
+    for kw in ({"gl_form": "sometimes"}, {"frame_engine": "fastest"}, {"plan_layout": "dense"}, {"imel_form": "fast"}):
         with pytest.raises(ValueError):
             _hip.Plan(SpectrogramParams(sample_rate=48000), "cpu", **kw)

@@ -95,7 +95,7 @@ def test_plan_cache_is_bounded_least_recently_used(monkeypatch):
     made, closed = [], []
 
     class FakePlan:
-        def __init__(self, params, dev, gl_form, frame_engine, plan_layout):
+        def __init__(self, params, dev, gl_form, frame_engine, plan_layout, imel_form):
             self.key = (params.max_mel_iters, gl_form, frame_engine, plan_layout)
             made.append(self.key)
 
