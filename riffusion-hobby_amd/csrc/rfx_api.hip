@@ -543,12 +543,13 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
         }
         // wave kernel (rfx_imel.hip::imel_wave_kernel): 512 groups dealt to 64 lanes in eight chunks whose budgets must hold every
         // group, weights linear in the bin index inside a group (least-squares line in double, checked per bin), unit form in the
-        // upper four chunks, and a step count its padding slots survive (buffer -1e37 decaying by the momentum 0.9 per step)
-        wave_ok = RFX_IMEL_WAVE && opt.imel_form == RFX_IMEL_FORM_AUTO && fast_code == 2 && unit_form && M == 64 * rfx::kImelWaveChunks &&
-                  (double)params->max_mel_iters * 0.045757490560675115 <= 28.0;
+        // upper four chunks
+        wave_ok = RFX_IMEL_WAVE && opt.imel_form == RFX_IMEL_FORM_AUTO && fast_code == 2 && unit_form && M == 64 * rfx::kImelWaveChunks;
         for (int c = 0; c < rfx::kImelWaveChunks && wave_ok; ++c)
-          for (int lane = 0; lane < 64; ++lane)
-            if (cnt[rfx::imel_wave_group(c, lane)] > 2 * rfx::kImelWavePairs[c]) wave_ok = false;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int n = cnt[rfx::imel_wave_group(c, lane)];
+            if (n > 2 * rfx::kImelWavePairs[c] || n < 2 * rfx::kImelWaveFullPairs[c]) wave_ok = false;
+          }
         lin.assign(4 * (size_t)M, 0.f);
         for (int g2 = 0; g2 < M && wave_ok; ++g2) {
           const int n = cnt[g2], f0 = grp_start[g2];

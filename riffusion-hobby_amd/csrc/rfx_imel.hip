@@ -566,21 +566,29 @@ imel_group_kernel_perwave(ImelArgs a) {
 //  * every lane carries 60 - 67 of the 4000 active bins although a group grows from 1 to 23 bins over the bank,
 //  * the neighbours g - 1 and g + 1 of a lane's group sit in the adjacent lane (one DPP wave shift each) or, where two chunks
 //    meet, in the lane itself (the `old` operand of the same DPP instruction: the shift leaves the end lane untouched),
-//  * all state of the frame - 82 slots x (spec, momentum buffer) - stays in the wave's 256 VGPRs at two waves per SIMD.
-// What makes that fit is that the weights need no registers: on a uniform bin grid a triangular filter's weight is LINEAR in
-// the bin index inside a group, w0 = a0 + s0 i, w1 = a1 + s1 i (fitted in double and checked against the table to 1e-6 per bin at
-// plan creation, ImelTables::lin), so with S = sum x_i and Q = sum i x_i
-//      A = a0 S + s0 Q,  B = a1 S + s1 Q  (unit form, chunks 4 - 7: B = S - A)
-//      gradient of bin i = (d0 a0 + d1 a1) + (d0 s0 + d1 s1) i  =: cc + st i
-// and a PAIR of bins (2p, 2p + 1) costs five packed instructions per step like before: S += x; Q += p x (Q = 2 (Qx + Qy) + Sy);
-// t = fma(p, (2 st, 2 st), (cc, cc + st)); buf = fma(mom, buf, t); x = clamp(fma(-lr g, buf, x)) - minus the p = 0 and p = 1
-// terms that need no arithmetic (173 packed instructions per frame and step; 209 in the group kernels).  The state is the
-// scaled one of the group kernels (2^-60, output clamp), the residuals are formed in the same order.
-// Padding slots (a lane's group is shorter than its chunk's budget) hold x = 0 and a momentum buffer that starts at -1e37:
-// it decays by `momentum` per step, stays far below anything the gradient adds for the step counts plan creation admits
-// (momentum^max_iter >= 1e-28), and so keeps x clamped at exactly zero, out of S and Q, without a mask or a branch.
-// Numerics: not bit-identical to the group kernels (weights from the line instead of the table: <= 1 ulp of 1.0 apart; sums in
-// another order); emulated in numpy against the oracle rel-L2 3.1e-7 after 120 steps (table weights: 2.1e-7), gate 1e-3.
+//  * all state of the frame stays in the wave's VGPRs at two waves per SIMD.
+// Two observations make the state small and the step cheap:
+//  1. on a uniform bin grid a triangular filter's weight is LINEAR in the bin index inside a group, w0 = a0 + s0 i,
+//     w1 = a1 + s1 i (least-squares line in double, checked against the table to 1e-6 per bin at plan creation,
+//     ImelTables::lin), so with S = sum x_i and Q = sum i x_i
+//        A = a0 S + s0 Q,  B = a1 S + s1 Q  (unit form, chunks 4 - 7: B = S - A)
+//        gradient of bin i = (d0 a0 + d1 a1) + (d0 s0 + d1 s1) i  =: cc + st i        - no weight registers;
+//  2. the gradient is a line in i, the momentum buffer starts at zero and torch.optim.SGD updates it linearly
+//     (buf <- momentum buf + grad, whatever the clamp does to x afterwards), so the buffer of a group's bin i IS the line
+//     C + G i with C <- momentum C + cc, G <- momentum G + st: two scalars per group instead of a register per bin.
+// A PAIR of bins (2p, 2p + 1) then costs four packed instructions per step - S += x; Q += p x (Q = 2 (Qx + Qy) + Sy);
+// v = fma(p, (2 h, 2 h), (-lr g C, -lr g C + h)) with h = -lr g G; x = clamp(x + v) - minus the p = 0 and p = 1 terms that need
+// no arithmetic: 132 packed instructions per frame and step where the group kernels issue 209.  The state is the scaled one
+// of the group kernels (2^-60, output clamp), the residuals are formed in the same order.
+// Padding slots (a lane's group is shorter than its chunk's budget) hold x = 0 and their step is multiplied by a per-lane
+// 0 / 1 mask (x = clamp(fma(v, mask, x))) - only the pairs behind kImelWaveFullPairs can be padding and carry one.
+// The per-step loss (sum of the squared residuals over the frame's filters, read by imel_scan_kernel) is summed by the LDS
+// unit (ds_add_f32 of all lanes into one word: the unit is otherwise idle here), not by six DPP steps on the VALU.
+// Numerics: not bit-identical to the group kernels (weights and buffer from lines: <= 1 ulp of 1.0 apart; sums in another
+// order); emulated in numpy against the oracle (tests/test_imel_wave_form.py) rel-L2 3.1e-7 after 120 steps (table weights:
+// 2.1e-7), on the device 8.9e-8 against the group kernels at T = 512, gate 1e-3.
+// Measured per VALU instruction and SIMD at two waves per SIMD (tools/ubench/valu_rate.hip): v_pk_fma_f32 2.4 ns, v_fma_f32 1.5,
+// v_mov_b32_dpp wave_shr 2.1: the kernel runs at the sum of its instructions' costs, i.e. the count is what is left to cut.
 // ---------------------------------------------------------------------------------------------------
 #if RFX_IMEL_PK
 constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
@@ -589,17 +597,31 @@ template <int CTRL>
 __device__ __forceinline__ float wave_shift(float old, float src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
 }
-constexpr float kWvPadBuf = -1e37f;
+// x = clamp(x + v, 0, 1) / x = clamp(x + v m, 0, 1): the packed instruction's output clamp (see pk_step_clamp)
+__device__ __forceinline__ c2 pk_add_clamp(c2 x, c2 v) {
+  asm("v_pk_add_f32 %0, %0, %1 clamp" : "+v"(x) : "v"(v));
+  return x;
+}
+__device__ __forceinline__ c2 pk_fma_clamp(c2 x, c2 v, c2 m) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 clamp" : "+v"(x) : "v"(v), "v"(m));
+  return x;
+}
 
-template <int NP, bool UF>
+// x = m x + c written over x (hipcc picks v_fmac, whose result lands in c's register, and copies it back every trip of the loop)
+__device__ __forceinline__ void fma_in_place(float& x, unsigned m_sgpr, float c) { asm("v_fma_f32 %0, %1, %0, %2" : "+v"(x) : "s"(m_sgpr), "v"(c)); }
+
+template <int NP, int NF, bool UF>  // NP pairs of slots, the first NF of them full in every lane
 struct WvChunk {
-  c2 spec[NP], buf[NP];
+  static constexpr int NT = NP - NF;
+  c2 spec[NP];
+  c2 mask[NT > 0 ? NT : 1];
   float a0, s0, a1, s1;  // a1, s1 unused in unit form
   float m0;              // scaled mel target of filter g
+  float C, G;            // the momentum buffer of the group's bin i is C + G i, in units of the STEP (-lr x gradient scale folded in)
 };
 
-template <int NP, bool UF>
-__device__ __forceinline__ void wv_load(WvChunk<NP, UF>& k, int g, const ImelArgs& a, int frame, int b, int t, unsigned rbase) {
+template <int NP, int NF, bool UF>
+__device__ __forceinline__ void wv_load(WvChunk<NP, NF, UF>& k, int g, const ImelArgs& a, int frame, int b, int t, unsigned rbase) {
   const ImelTables& tb = a.tb;
   const int f0 = tb.grp_start[g], n = tb.grp_start[g + 1] - f0;
   k.a0 = tb.lin[g];
@@ -607,22 +629,24 @@ __device__ __forceinline__ void wv_load(WvChunk<NP, UF>& k, int g, const ImelArg
   k.a1 = tb.lin[2 * a.M + g];
   k.s1 = tb.lin[3 * a.M + g];
   k.m0 = kImelScale * a.mel[((size_t)b * a.M + g) * a.T + t];
+  k.C = 0.f;
+  k.G = 0.f;
 #pragma unroll
   for (int i = 0; i < 2 * NP; ++i) {
     const bool ok = i < n;
     const int f = f0 + (ok ? i : 0);
     const float sp = ok ? kImelScale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
-    const float bf = ok ? 0.f : kWvPadBuf;
-    if (i & 1) { k.spec[i >> 1].y = sp; k.buf[i >> 1].y = bf; }
-    else       { k.spec[i >> 1].x = sp; k.buf[i >> 1].x = bf; }
+    if (i & 1) k.spec[i >> 1].y = sp; else k.spec[i >> 1].x = sp;
+    if (i >= 2 * NF) {
+      if (i & 1) k.mask[(i >> 1) - NF].y = ok ? 1.f : 0.f; else k.mask[(i >> 1) - NF].x = ok ? 1.f : 0.f;
+    }
   }
 }
-// The step is written phase by phase ACROSS chunks - the compiler keeps the source order of independent instructions, and a
-// dependent VALU instruction issued right behind its producer stalls the wave (only two waves share a SIMD here): the packed sums
-// of two chunks advance together (four accumulator chains), the scalar tails of four chunks at a time, and the update forms all
-// of a chunk's gradient pairs before its buffers and all buffers before the clamped steps.
-template <int NPA, int NPB, bool UFA, bool UFB>
-__device__ __forceinline__ void wv_sums2(const WvChunk<NPA, UFA>& ka, const WvChunk<NPB, UFB>& kb, c2& SA, c2& QA, c2& SB, c2& QB) {
+// The step is written phase by phase ACROSS chunks - the compiler keeps the source order of independent instructions: the
+// packed sums of two chunks advance together (four accumulator chains), the scalar tails of four chunks at a time, and the
+// update forms all of a chunk's step pairs before it applies them.
+template <int NPA, int NFA, int NPB, int NFB, bool UFA, bool UFB>
+__device__ __forceinline__ void wv_sums2(const WvChunk<NPA, NFA, UFA>& ka, const WvChunk<NPB, NFB, UFB>& kb, c2& SA, c2& QA, c2& SB, c2& QB) {
   static_assert(NPA >= 2 && NPB >= 2, "every chunk holds at least two pairs");
   SA = ka.spec[0] + ka.spec[1];
   SB = kb.spec[0] + kb.spec[1];
@@ -636,21 +660,19 @@ __device__ __forceinline__ void wv_sums2(const WvChunk<NPA, UFA>& ka, const WvCh
     if (p < NPB) QB = __builtin_elementwise_fma(bc2((float)p), kb.spec[p], QB);
   }
 }
-// t_p = (cc, cc + st) + p (2 st, 2 st) for every pair of the chunk, then the buffers, then the clamped steps
-template <int NP, bool UF>
-__device__ __forceinline__ void wv_update(WvChunk<NP, UF>& k, float cc, float cs, float st2, float mom, unsigned long long nl2) {
-  const c2 base = c2{cc, cs}, s2 = bc2(st2), vm = bc2(mom);
-  c2 t[NP];
-  t[0] = base;
+// step of the pair p: v_p = (vx, vy) + p (w2, w2) with vx = C, vy = C + G, w2 = 2 G
+template <int NP, int NF, bool UF>
+__device__ __forceinline__ void wv_update(WvChunk<NP, NF, UF>& k, float vx, float vy, float w2) {
+  const c2 base = c2{vx, vy}, s2 = bc2(w2);
+  c2 v[NP];
+  v[0] = base;
 #pragma unroll
-  for (int p = 1; p < NP; ++p) t[p] = __builtin_elementwise_fma(bc2((float)p), s2, base);
+  for (int p = 1; p < NP; ++p) v[p] = __builtin_elementwise_fma(bc2((float)p), s2, base);
 #pragma unroll
-  for (int p = 0; p < NP; ++p) k.buf[p] = __builtin_elementwise_fma(vm, k.buf[p], t[p]);  // torch.optim.SGD: buf.mul_(momentum).add_(grad)
-#pragma unroll
-  for (int p = 0; p < NP; ++p) k.spec[p] = pk_step_clamp(k.spec[p], nl2, k.buf[p]);
+  for (int p = 0; p < NP; ++p) k.spec[p] = p < NF ? pk_add_clamp(k.spec[p], v[p]) : pk_fma_clamp(k.spec[p], v[p], k.mask[p < NF ? 0 : p - NF]);
 }
-template <int NP, bool UF>
-__device__ __forceinline__ void wv_store(const WvChunk<NP, UF>& k, int g, const ImelTables& tb, float* out) {
+template <int NP, int NF, bool UF>
+__device__ __forceinline__ void wv_store(const WvChunk<NP, NF, UF>& k, int g, const ImelTables& tb, float* out) {
   const int f0 = tb.grp_start[g], n = tb.grp_start[g + 1] - f0;
 #pragma unroll
   for (int i = 0; i < 2 * NP; ++i)
@@ -664,6 +686,8 @@ __device__ __forceinline__ void wv_store(const WvChunk<NP, UF>& k, int g, const 
 }
 
 #define RFX_WV_CHUNKS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define RFX_WV_LO(X) X(0) X(1) X(2) X(3)
+#define RFX_WV_HI(X) X(4) X(5) X(6) X(7)
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) imel_wave_kernel(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -675,23 +699,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
   const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
+  for (int i = lane; i < a.max_iter; i += 64) part[i] = 0.f;
+  const unsigned part_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address of part[0]
 
-  WvChunk<kImelWavePairs[0], false> k0;
-  WvChunk<kImelWavePairs[1], false> k1;
-  WvChunk<kImelWavePairs[2], false> k2;
-  WvChunk<kImelWavePairs[3], false> k3;
-  WvChunk<kImelWavePairs[4], true> k4;
-  WvChunk<kImelWavePairs[5], true> k5;
-  WvChunk<kImelWavePairs[6], true> k6;
-  WvChunk<kImelWavePairs[7], true> k7;
+#define RFX_WV_DECL(c, UF) WvChunk<kImelWavePairs[c], kImelWaveFullPairs[c], UF> k##c;
+  RFX_WV_DECL(0, false) RFX_WV_DECL(1, false) RFX_WV_DECL(2, false) RFX_WV_DECL(3, false)
+  RFX_WV_DECL(4, true) RFX_WV_DECL(5, true) RFX_WV_DECL(6, true) RFX_WV_DECL(7, true)
+#undef RFX_WV_DECL
 #define RFX_WV_LOAD(c) wv_load(k##c, imel_wave_group(c, lane), a, frame, b, t, rbase);
   RFX_WV_CHUNKS(RFX_WV_LOAD)
 #undef RFX_WV_LOAD
 
-  const float lrg = a.lr * (-2.0f / (float)(a.C * a.T));  // the step in units of the gradient scale -2 / (C T), see imel_group_body
-  const unsigned nlb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, -lrg));
-  const unsigned long long nl2 = ((unsigned long long)nlb << 32) | nlb;
-  const float mom = a.momentum;
+  const float nl = -(a.lr * (-2.0f / (float)(a.C * a.T)));  // the step in units of the gradient scale -2 / (C T), see imel_group_body
+  const unsigned mom_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.momentum));
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the zeroed loss words (one wave per workgroup: no barrier needed)
 
   for (int it = 0; it < steps; ++it) {
     float A0, A1, A2, A3, A4, A5, A6, A7, B0, B1, B2, B3, B4, B5, B6, B7;
@@ -699,29 +720,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       c2 S0, Q0, S1, Q1, S2, Q2, S3, Q3;
       wv_sums2(k0, k1, S0, Q0, S1, Q1);
       wv_sums2(k2, k3, S2, Q2, S3, Q3);
-#define RFX_WV4(X) X(0) X(1) X(2) X(3)
 #define RFX_WV_T1(c) const float s##c = S##c.x + S##c.y, h##c = Q##c.x + Q##c.y;
 #define RFX_WV_T2(c) const float q##c = fmaf(2.f, h##c, S##c.y), e##c = k##c.a0 * s##c, g##c = k##c.a1 * s##c;
 #define RFX_WV_T3(c) A##c = fmaf(k##c.s0, q##c, e##c); B##c = fmaf(k##c.s1, q##c, g##c);
-      RFX_WV4(RFX_WV_T1) RFX_WV4(RFX_WV_T2) RFX_WV4(RFX_WV_T3)
+      RFX_WV_LO(RFX_WV_T1) RFX_WV_LO(RFX_WV_T2) RFX_WV_LO(RFX_WV_T3)
 #undef RFX_WV_T2
 #undef RFX_WV_T3
-#undef RFX_WV4
     }
     {
       c2 S4, Q4, S5, Q5, S6, Q6, S7, Q7;
       wv_sums2(k4, k5, S4, Q4, S5, Q5);
       wv_sums2(k6, k7, S6, Q6, S7, Q7);
-#define RFX_WV4(X) X(4) X(5) X(6) X(7)
 #define RFX_WV_T2(c) const float q##c = fmaf(2.f, h##c, S##c.y), e##c = k##c.a0 * s##c;
 #define RFX_WV_T3(c) A##c = fmaf(k##c.s0, q##c, e##c);
 #define RFX_WV_T4(c) B##c = s##c - A##c;
-      RFX_WV4(RFX_WV_T1) RFX_WV4(RFX_WV_T2) RFX_WV4(RFX_WV_T3) RFX_WV4(RFX_WV_T4)
+      RFX_WV_HI(RFX_WV_T1) RFX_WV_HI(RFX_WV_T2) RFX_WV_HI(RFX_WV_T3) RFX_WV_HI(RFX_WV_T4)
 #undef RFX_WV_T1
 #undef RFX_WV_T2
 #undef RFX_WV_T3
 #undef RFX_WV_T4
-#undef RFX_WV4
     }
     // B of group g - 1: the previous lane of an even chunk (wave_shr), the next lane of an odd one (wave_shl); the end lane's
     // predecessor is the previous chunk's group in the lane itself.  Residual of filter g: d0 = (mel_g - A_g) - B_{g-1}
@@ -734,32 +751,43 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define RFX_WV_R2(c) const float d0##c = r##c - p##c;
     RFX_WV_CHUNKS(RFX_WV_R2)
 #undef RFX_WV_R2
-    // residual of filter g + 1 = the d0 of the next group: the next lane of an even chunk, the previous lane of an odd one, the
-    // following chunk's in the end lane; filter 512 does not exist (chunk 7, lane 0: zero)
-    const float d10 = wave_shift<kDppWaveShl1>(d01, d00), d11 = wave_shift<kDppWaveShr1>(d02, d01), d12 = wave_shift<kDppWaveShl1>(d03, d02),
-                d13 = wave_shift<kDppWaveShr1>(d04, d03), d14 = wave_shift<kDppWaveShl1>(d05, d04), d15 = wave_shift<kDppWaveShr1>(d06, d05),
-                d16 = wave_shift<kDppWaveShl1>(d07, d06), d17 = wave_shift<kDppWaveShr1>(0.f, d07);
 #ifndef RFX_ABL_IMEL_NO_LOSS
     {  // every filter's residual is owned exactly once; the loss history is kept in the reference's units
 #define RFX_WV_L1(c) const float u##c = kImelUnscale * d0##c;
       RFX_WV_CHUNKS(RFX_WV_L1)
 #undef RFX_WV_L1
       const float sqa = fmaf(u6, u6, fmaf(u4, u4, fmaf(u2, u2, u0 * u0))), sqb = fmaf(u7, u7, fmaf(u5, u5, fmaf(u3, u3, u1 * u1)));
-      part[it] = wave_sum(sqa + sqb);  // wave-uniform: all lanes write the same word
+      // one ds_add_f32 of all 64 lanes into the step's word: the LDS unit adds them (written as asm: the compiler's atomic
+      // optimizer would replace a uniform-address atomic by a 64-trip v_readlane loop on the VALU)
+      asm volatile("ds_add_f32 %0, %1" ::"v"(part_lds + 4u * (unsigned)it), "v"(sqa + sqb) : "memory");
     }
 #endif
+    // From here on the residuals carry the step factor -lr g (n = -lr g d): everything below is linear in them, so the buffer
+    // line (C, G) is kept in step units and needs no further scaling
+#define RFX_WV_N0(c) const float n0##c = nl * d0##c;
+    RFX_WV_CHUNKS(RFX_WV_N0)
+#undef RFX_WV_N0
+    // residual of filter g + 1 = that of the next group: the next lane of an even chunk, the previous lane of an odd one, the
+    // following chunk's in the end lane; filter 512 does not exist (chunk 7, lane 0: zero)
+    const float n10 = wave_shift<kDppWaveShl1>(n01, n00), n11 = wave_shift<kDppWaveShr1>(n02, n01), n12 = wave_shift<kDppWaveShl1>(n03, n02),
+                n13 = wave_shift<kDppWaveShr1>(n04, n03), n14 = wave_shift<kDppWaveShl1>(n05, n04), n15 = wave_shift<kDppWaveShr1>(n06, n05),
+                n16 = wave_shift<kDppWaveShl1>(n07, n06), n17 = wave_shift<kDppWaveShr1>(0.f, n07);
     // gradient line of every chunk: bin i of the group gets cc + st i (both weights: chunks 0 - 3; unit form: 4 - 7)
-    const float dd4 = d04 - d14, dd5 = d05 - d15, dd6 = d06 - d16, dd7 = d07 - d17;
-    const float x0 = d00 * k0.a0, x1 = d01 * k1.a0, x2 = d02 * k2.a0, x3 = d03 * k3.a0;
-    const float y0 = d00 * k0.s0, y1 = d01 * k1.s0, y2 = d02 * k2.s0, y3 = d03 * k3.s0;
-    const float cc0 = fmaf(d10, k0.a1, x0), cc1 = fmaf(d11, k1.a1, x1), cc2 = fmaf(d12, k2.a1, x2), cc3 = fmaf(d13, k3.a1, x3);
-    const float st0 = fmaf(d10, k0.s1, y0), st1 = fmaf(d11, k1.s1, y1), st2 = fmaf(d12, k2.s1, y2), st3 = fmaf(d13, k3.s1, y3);
-    const float cc4 = fmaf(dd4, k4.a0, d14), cc5 = fmaf(dd5, k5.a0, d15), cc6 = fmaf(dd6, k6.a0, d16), cc7 = fmaf(dd7, k7.a0, d17);
+    const float dd4 = n04 - n14, dd5 = n05 - n15, dd6 = n06 - n16, dd7 = n07 - n17;
+    const float x0 = n00 * k0.a0, x1 = n01 * k1.a0, x2 = n02 * k2.a0, x3 = n03 * k3.a0;
+    const float y0 = n00 * k0.s0, y1 = n01 * k1.s0, y2 = n02 * k2.s0, y3 = n03 * k3.s0;
+    const float cc0 = fmaf(n10, k0.a1, x0), cc1 = fmaf(n11, k1.a1, x1), cc2 = fmaf(n12, k2.a1, x2), cc3 = fmaf(n13, k3.a1, x3);
+    const float st0 = fmaf(n10, k0.s1, y0), st1 = fmaf(n11, k1.s1, y1), st2 = fmaf(n12, k2.s1, y2), st3 = fmaf(n13, k3.s1, y3);
+    const float cc4 = fmaf(dd4, k4.a0, n14), cc5 = fmaf(dd5, k5.a0, n15), cc6 = fmaf(dd6, k6.a0, n16), cc7 = fmaf(dd7, k7.a0, n17);
     const float st4 = dd4 * k4.s0, st5 = dd5 * k5.s0, st6 = dd6 * k6.s0, st7 = dd7 * k7.s0;
-#define RFX_WV_G1(c) const float cs##c = cc##c + st##c, tw##c = st##c + st##c;
-    RFX_WV_CHUNKS(RFX_WV_G1)
+    // torch.optim.SGD: buf.mul_(momentum).add_(grad) for every bin of the group at once - the buffer line (C, G), in place -
+    // then the step of the pair p: (C, C + G) + p (2 G, 2 G)
+#define RFX_WV_G1(c) fma_in_place(k##c.C, mom_s, cc##c); fma_in_place(k##c.G, mom_s, st##c);
+#define RFX_WV_G3(c) const float vx##c = k##c.C, vy##c = k##c.C + k##c.G, w2##c = k##c.G + k##c.G;
+    RFX_WV_CHUNKS(RFX_WV_G1) RFX_WV_CHUNKS(RFX_WV_G3)
 #undef RFX_WV_G1
-#define RFX_WV_UPDATE(c) wv_update(k##c, cc##c, cs##c, tw##c, mom, nl2);
+#undef RFX_WV_G3
+#define RFX_WV_UPDATE(c) wv_update(k##c, vx##c, vy##c, w2##c);
     RFX_WV_CHUNKS(RFX_WV_UPDATE)
 #undef RFX_WV_UPDATE
   }
@@ -784,11 +812,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
   if (a.loss_hist && !a.it_limit) {
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes (one wave per workgroup: no barrier needed)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS atomics
     for (int i = lane; i < a.max_iter; i += 64) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? part[i] : 0.f;
   }
 }
 #undef RFX_WV_CHUNKS
+#undef RFX_WV_LO
+#undef RFX_WV_HI
 #endif  // RFX_IMEL_PK
 
 // one workgroup per clip: replays the reference's stopping rule on the clip-mean loss.  Thread (g, i) sums

@@ -123,6 +123,9 @@ constexpr int kImelHiCapWide[4] = {26, 17, 12, 9};
 // in the adjacent lane (a DPP wave shift) or, at the chunk seams, in the lane itself.  Budget per chunk in register PAIRS:
 constexpr int kImelWaveChunks = 8;
 constexpr int kImelWavePairs[kImelWaveChunks] = {2, 2, 3, 3, 5, 6, 8, 12};
+// leading pairs that EVERY lane of the chunk fills (plan creation checks n >= 2 full for each group); the pairs behind them carry a
+// per-lane 0 / 1 mask for the slots a shorter group leaves empty
+constexpr int kImelWaveFullPairs[kImelWaveChunks] = {0, 1, 1, 2, 3, 4, 5, 8};
 RFX_HD int imel_wave_group(int chunk, int lane) { return (chunk & 1) ? 64 * chunk + 63 - lane : 64 * chunk + lane; }
 #ifndef RFX_IMEL_WAVE
 #define RFX_IMEL_WAVE 1  // 0: build without selecting the wave kernel (A/B against the group kernels)
@@ -148,7 +151,7 @@ struct ImelTables {
   const float* lin;      // [4][M] a0 | s0 | a1 | s1: within group g the weights are w0 = a0 + s0 i, w1 = a1 + s1 i for the group's i-th bin
                          // (triangular filters on a uniform bin grid; fitted and checked to 1e-6 per bin at plan creation)
   int wave_ok;           // 1: imel_wave_kernel serves this bank (M == 512, the chunk budgets fit, the weights are linear per group, unit
-                         // form holds, and max_mel_iters is within the range the padding trick of the kernel covers)
+                         // form holds)
 };
 struct ImelArgs {
   ImelTables tb;

@@ -152,22 +152,22 @@ def test_wave_formulation_tracks_the_oracle():
                 old = B[c - 1] if c else zero
                 bp = _shift_from_next(old, B[c]) if c & 1 else _shift_from_prev(old, B[c])
                 d0.append(((m0[c] - A[c]).astype(f32) - bp).astype(f32))
-            d1 = []
+            n0 = [(nl * d0[c]).astype(f32) for c in range(8)]  # residuals in units of the step -lr g: everything below is linear in them
+            n1 = []
             for c in range(8):
-                old = d0[c + 1] if c < 7 else zero
-                d1.append(_shift_from_prev(old, d0[c]) if c & 1 else _shift_from_next(old, d0[c]))
+                old = n0[c + 1] if c < 7 else zero
+                n1.append(_shift_from_prev(old, n0[c]) if c & 1 else _shift_from_next(old, n0[c]))
             for c in range(8):
                 if c >= 4:
-                    dd = (d0[c] - d1[c]).astype(f32)
-                    cc = (dd * A0[c][:, 0] + d1[c]).astype(f32)
+                    dd = (n0[c] - n1[c]).astype(f32)
+                    cc = (dd * A0[c][:, 0] + n1[c]).astype(f32)
                     st = (dd * A0[c][:, 1]).astype(f32)
                 else:
-                    cc = (d1[c] * A1[c][:, 0] + (d0[c] * A0[c][:, 0]).astype(f32)).astype(f32)
-                    st = (d1[c] * A1[c][:, 1] + (d0[c] * A0[c][:, 1]).astype(f32)).astype(f32)
+                    cc = (n1[c] * A1[c][:, 0] + (n0[c] * A0[c][:, 0]).astype(f32)).astype(f32)
+                    st = (n1[c] * A1[c][:, 1] + (n0[c] * A0[c][:, 1]).astype(f32)).astype(f32)
                 Cc[c] = (mom * Cc[c] + cc).astype(f32)  # torch.optim.SGD: buf.mul_(momentum).add_(grad), for the whole line at once
                 Gg[c] = (mom * Gg[c] + st).astype(f32)
-                vx = (nl * Cc[c]).astype(f32)
-                h = (nl * Gg[c]).astype(f32)
+                vx, h = Cc[c], Gg[c]
                 base = np.stack([vx, (vx + h).astype(f32)], 1)
                 w2 = (h + h).astype(f32)[:, None]
                 for pp in range(PAIRS[c]):
