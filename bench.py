@@ -165,6 +165,17 @@ def valu_binding(valu_instr_per_launch: float, launch_ms: float, mix: dict, pmc:
         clk = gui / 8.0 / (busy_ms * 1e-3) / 1e9
         out["measured_clock_ghz"] = round(clk, 3)
         out["frac_at_measured_clock"] = round(got / (1024 * clk), 4)
+    # Third reading (round 4, late): what the SIMDs were MEASURED to sustain per instruction kind with nothing else in their way
+    # (tools/ubench/valu_rate.hip, profiles/r04_valu_rate_ubench.txt, four waves per SIMD): v_fma / v_add 1.47 ns, v_pk_* 2.28 ns,
+    # quarter-rate 3.5 ns per wave-instruction and SIMD - a packed instruction costs 1.55 plain ones, not 2 x 2 cycles / 2.4 GHz.
+    # `frac_of_measured_instruction_rate` = the launch's VALU work priced that way / launch time, averaged over the 1024 SIMDs (the
+    # SIMDs that carry four of a CU's fourteen waves sit 14 % above the average).
+    lm = mix.get("loop_mix") or {}
+    n_loop = lm.get("valu_plain", 0) + lm.get("valu_packed", 0) + lm.get("valu_quarter_rate", 0)
+    if n_loop:
+        ns_per_instr = (1.47 * lm.get("valu_plain", 0) + 2.28 * lm.get("valu_packed", 0) + 3.5 * lm.get("valu_quarter_rate", 0)) / n_loop
+        out["measured_ns_per_valu_instruction"] = round(ns_per_instr, 3)
+        out["frac_of_measured_instruction_rate"] = round(valu_instr_per_launch / 1024.0 * ns_per_instr * 1e-6 / launch_ms, 4)
     return out
 
 
