@@ -1,6 +1,7 @@
 """
-Instruction mix of the frame loop of the two dominant kernels, counted in the ISA hipcc emits for gfx950 (no GPU needed):
-rfx::gl_iter_kernel<2> (csrc/rfx_gl.hip) and rfx::stft_mel2_kernel (csrc/rfx_stft.hip).  Since round 4 most butterfly
+Instruction mix of the frame loop of the dominant kernels, counted in the ISA hipcc emits for gfx950 (no GPU needed):
+rfx::gl_iter_kernel<2> (csrc/rfx_gl.hip), rfx::stft_mel2_kernel (csrc/rfx_stft.hip) and the SGD step loop of rfx::imel_wave_kernel
+(csrc/rfx_imel.hip).  Since round 4 most butterfly
 arithmetic is packed (v_pk_*_f32 on (re, im) pairs): a packed instruction is ONE issue slot but occupies the SIMD's fp32 pipe
 for 4 cycles where a plain one takes 2 (MI355X_MICROARCH.md; quarter-rate v_rsq / v_sqrt / v_rcp: 8), so the count of wave
 instructions no longer measures the VALU time a kernel needs.  bench.py's `binding` roofline multiplies the PMC count of VALU
@@ -13,7 +14,9 @@ import collections, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "riffusion-hobby_amd", "csrc")
 KERNELS = [("rfx_gl.hip", "_ZN3rfx14gl_iter_kernelILi2EEEvNS_6GlArgsE", "rfx::gl_iter_kernel<2>"),
-           ("rfx_stft.hip", "_ZN3rfx16stft_mel2_kernelILj2031647EEEvNS_11StftMelArgsE", "rfx::stft_mel2_kernel<0x1F001F>")]
+           ("rfx_stft.hip", "_ZN3rfx16stft_mel2_kernelILj2031647EEEvNS_11StftMelArgsE", "rfx::stft_mel2_kernel<0x1F001F>"),
+           # one trip = one SGD step of one frame (one wave); its 16 DPP wave shifts count as plain here (measured 2.1 ns each)
+           ("rfx_imel.hip", "_ZN3rfx16imel_wave_kernelENS_8ImelArgsE", "rfx::imel_wave_kernel")]
 TRANS = {"v_rsq_f32_e32", "v_rcp_f32_e32", "v_sqrt_f32_e32", "v_rsq_f32_e64", "v_rcp_f32_e64", "v_sqrt_f32_e64"}
 
 
