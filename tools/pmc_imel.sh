@@ -34,7 +34,7 @@ for key, c in rows.items():
 dur = []
 for f in sorted(glob.glob("$OUT/p*/*kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        if r.get("Kernel_Name", "") == kernel and int(r.get("Grid_Size", 0) or 0) in (B * T * THREADS, B * T * 64):
+        if r.get("Kernel_Name", "") == kernel and int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) in (B * T * THREADS, B * T * 64):
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 dur = [d for d in dur if d > 1.0]  # (the fix-up launch exits at once)
 res = {"kernel": kernel, "duration_ms_under_pmc": sum(dur) / max(1, len(dur)), "batch_tiles": B, "frames_per_tile": T,
