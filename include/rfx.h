@@ -187,7 +187,7 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
  * own layout, NULL = U[0,1) from `seed`.  Output: linear magnitudes in slot layout, ready for
  * rfx_griffinlim. */
 /* which SGD kernel rfx_inverse_mel runs for this plan's filterbank: 4 = wave kernel (one wave per frame, weights as a line per
- * group: the default 512-filter HTK bank without normalisation), 2 = group kernel with per-wave register budgets sized to
+ * group: the default 512-filter HTK bank, with or without slaney normalisation), 2 = group kernel with per-wave register budgets sized to
  * the default 512-filter HTK bank (with or without slaney normalisation), 3 = the same kernel with the wider budget set
  * (mel_scale_type "slaney"), 1 = group kernel with a uniform budget (other banks whose groups fit 8 / 24 bins),
  * 0 = general LDS kernel (any banded bank), -1 = not banded (rfx_inverse_mel refuses) */

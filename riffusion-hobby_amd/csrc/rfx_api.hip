@@ -542,9 +542,9 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
           else unit_form = fabsf(bin_w0[f] + bin_w1[f] - 1.f) <= 1e-6f;
         }
         // wave kernel (rfx_imel.hip::imel_wave_kernel): 512 groups dealt to 64 lanes in eight chunks whose budgets must hold every
-        // group, weights linear in the bin index inside a group (least-squares line in double, checked per bin), unit form in the
-        // upper four chunks
-        wave_ok = RFX_IMEL_WAVE && opt.imel_form == RFX_IMEL_FORM_AUTO && fast_code == 2 && unit_form && M == 64 * rfx::kImelWaveChunks;
+        // group, weights linear in the bin index inside a group (least-squares line in double, checked per bin); with the unit form
+        // (no area normalisation) the upper four chunks need one weight only
+        wave_ok = RFX_IMEL_WAVE && opt.imel_form == RFX_IMEL_FORM_AUTO && fast_code == 2 && M == 64 * rfx::kImelWaveChunks;
         for (int c = 0; c < rfx::kImelWaveChunks && wave_ok; ++c)
           for (int lane = 0; lane < 64; ++lane) {
             const int n = cnt[rfx::imel_wave_group(c, lane)];

@@ -571,7 +571,7 @@ imel_group_kernel_perwave(ImelArgs a) {
 //  1. on a uniform bin grid a triangular filter's weight is LINEAR in the bin index inside a group, w0 = a0 + s0 i,
 //     w1 = a1 + s1 i (least-squares line in double, checked against the table to 1e-6 per bin at plan creation,
 //     ImelTables::lin), so with S = sum x_i and Q = sum i x_i
-//        A = a0 S + s0 Q,  B = a1 S + s1 Q  (unit form, chunks 4 - 7: B = S - A)
+//        A = a0 S + s0 Q,  B = a1 S + s1 Q  (unit form, chunks 4 - 7 of a bank without area normalisation: B = S - A)
 //        gradient of bin i = (d0 a0 + d1 a1) + (d0 s0 + d1 s1) i  =: cc + st i        - no weight registers;
 //  2. the gradient is a line in i, the momentum buffer starts at zero and torch.optim.SGD updates it linearly
 //     (buf <- momentum buf + grad, whatever the clamp does to x afterwards), so the buffer of a group's bin i IS the line
@@ -689,6 +689,7 @@ __device__ __forceinline__ void wv_store(const WvChunk<NP, NF, UF>& k, int g, co
 #define RFX_WV_LO(X) X(0) X(1) X(2) X(3)
 #define RFX_WV_HI(X) X(4) X(5) X(6) X(7)
 
+template <bool UFH>  // unit form in the upper four chunks (triangles without area normalisation); false: both weights everywhere
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) imel_wave_kernel(ImelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* part = reinterpret_cast<float*>(smem);  // [max_iter] sum of diff^2 over the frame's filters, in the reference's units
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 #define RFX_WV_DECL(c, UF) WvChunk<kImelWavePairs[c], kImelWaveFullPairs[c], UF> k##c;
   RFX_WV_DECL(0, false) RFX_WV_DECL(1, false) RFX_WV_DECL(2, false) RFX_WV_DECL(3, false)
-  RFX_WV_DECL(4, true) RFX_WV_DECL(5, true) RFX_WV_DECL(6, true) RFX_WV_DECL(7, true)
+  RFX_WV_DECL(4, UFH) RFX_WV_DECL(5, UFH) RFX_WV_DECL(6, UFH) RFX_WV_DECL(7, UFH)
 #undef RFX_WV_DECL
 #define RFX_WV_LOAD(c) wv_load(k##c, imel_wave_group(c, lane), a, frame, b, t, rbase);
   RFX_WV_CHUNKS(RFX_WV_LOAD)
@@ -733,7 +734,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       wv_sums2(k6, k7, S6, Q6, S7, Q7);
 #define RFX_WV_T2(c) const float q##c = fmaf(2.f, h##c, S##c.y), e##c = k##c.a0 * s##c;
 #define RFX_WV_T3(c) A##c = fmaf(k##c.s0, q##c, e##c);
-#define RFX_WV_T4(c) B##c = s##c - A##c;
+#define RFX_WV_T4(c) B##c = UFH ? s##c - A##c : fmaf(k##c.s1, q##c, k##c.a1 * s##c);
       RFX_WV_HI(RFX_WV_T1) RFX_WV_HI(RFX_WV_T2) RFX_WV_HI(RFX_WV_T3) RFX_WV_HI(RFX_WV_T4)
 #undef RFX_WV_T1
 #undef RFX_WV_T2
@@ -778,8 +779,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const float y0 = n00 * k0.s0, y1 = n01 * k1.s0, y2 = n02 * k2.s0, y3 = n03 * k3.s0;
     const float cc0 = fmaf(n10, k0.a1, x0), cc1 = fmaf(n11, k1.a1, x1), cc2 = fmaf(n12, k2.a1, x2), cc3 = fmaf(n13, k3.a1, x3);
     const float st0 = fmaf(n10, k0.s1, y0), st1 = fmaf(n11, k1.s1, y1), st2 = fmaf(n12, k2.s1, y2), st3 = fmaf(n13, k3.s1, y3);
-    const float cc4 = fmaf(dd4, k4.a0, n14), cc5 = fmaf(dd5, k5.a0, n15), cc6 = fmaf(dd6, k6.a0, n16), cc7 = fmaf(dd7, k7.a0, n17);
-    const float st4 = dd4 * k4.s0, st5 = dd5 * k5.s0, st6 = dd6 * k6.s0, st7 = dd7 * k7.s0;
+#define RFX_WV_G0(c) const float cc##c = UFH ? fmaf(dd##c, k##c.a0, n1##c) : fmaf(n1##c, k##c.a1, n0##c * k##c.a0), \
+                                 st##c = UFH ? dd##c * k##c.s0 : fmaf(n1##c, k##c.s1, n0##c * k##c.s0);
+    RFX_WV_HI(RFX_WV_G0)
+#undef RFX_WV_G0
     // torch.optim.SGD: buf.mul_(momentum).add_(grad) for every bin of the group at once - the buffer line (C, G), in place -
     // then the step of the pair p: (C, C + G) + p (2 G, 2 G)
 #define RFX_WV_G1(c) fma_in_place(k##c.C, mom_s, cc##c); fma_in_place(k##c.G, mom_s, st##c);
@@ -879,7 +882,8 @@ static void launch_perwave(const ImelArgs& a, hipStream_t stream) {
 hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
 #if RFX_IMEL_PK && RFX_IMEL_WAVE
   if (a.tb.wave_ok && variant == 0) {  // one wave per frame (the fix-up pass too: its frames are independent of each other)
-    hipLaunchKernelGGL(imel_wave_kernel, dim3(a.B * a.T), dim3(64), sizeof(float) * (size_t)a.max_iter, stream, a);
+    if (a.tb.unit_form) hipLaunchKernelGGL(imel_wave_kernel<true>, dim3(a.B * a.T), dim3(64), sizeof(float) * (size_t)a.max_iter, stream, a);
+    else hipLaunchKernelGGL(imel_wave_kernel<false>, dim3(a.B * a.T), dim3(64), sizeof(float) * (size_t)a.max_iter, stream, a);
     return hipGetLastError();
   }
 #endif

@@ -97,10 +97,10 @@ def test_oracle_tile_from_inside_the_headline_batch(O):
     assert s_full >= 40.0  # the 1e-7-level SGD differences grow through 32 chaotic iterations
 
 
-@pytest.mark.parametrize("scale,norm,kernel", [("htk", "slaney", 2), ("slaney", None, None), ("slaney", "slaney", None)])
+@pytest.mark.parametrize("scale,norm,kernel", [("htk", "slaney", 4), ("slaney", None, None), ("slaney", "slaney", None)])
 def test_slaney_scale_and_norm(O, scale, norm, kernel):
     """The two mel parameters the reference exposes besides the defaults.  The normalised HTK bank has the default bank's
-    sparsity pattern and takes the per-wave group kernel; the slaney SCALE moves the filter edges (its largest group may exceed
+    sparsity pattern and takes the wave kernel with both weight lines in every chunk (its two weights per bin do not sum to one); the slaney SCALE moves the filter edges (its largest group may exceed
     the default budgets) and takes whichever kernel rfx_plan_imel_kernel reports."""
     from riffusion.spectrogram_params import SpectrogramParams
 
@@ -131,7 +131,7 @@ def test_slaney_scale_and_norm(O, scale, norm, kernel):
     act = _active_rows(O, op)
     rel = float(torch.linalg.norm(got[:, act] - want[:, act]) / torch.linalg.norm(want[:, act]))
     print(f"mel_scale_type={scale!r} mel_scale_norm={norm!r}: forward rel-L2 {rel_fwd:.2e}, InverseMelScale-60 rel-L2 {rel:.2e}, "
-          f"SGD kernel {which} (2 = per-wave groups, 1 = uniform groups, 0 = general), unit-form gradient {unit}")
+          f"SGD kernel {which} (4 = wave, 2 / 3 = per-wave groups, 1 = uniform groups, 0 = general), unit-form gradient {unit}")
     assert rel <= 1e-3 and torch.equal(got[:, ~act], want[:, ~act])
 
 

@@ -12,6 +12,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -100,8 +101,12 @@ def _shift_from_next(old, src):  # wave_shl:1 - lane i takes src of lane i + 1, 
     return out
 
 
-def test_wave_formulation_tracks_the_oracle():
-    p = O.OracleParams(max_mel_iters=120)
+@pytest.mark.parametrize("norm", [None, "slaney"])
+def test_wave_formulation_tracks_the_oracle(norm):
+    """norm None: unit form in the upper four chunks (B = S - A, one weight line); "slaney" (area-normalised triangles: still lines
+    per group, but the two weights of a bin no longer sum to one): both weight lines in every chunk."""
+    p = O.OracleParams(max_mel_iters=120, mel_scale_norm=norm)
+    uf = norm is None
     fb, act, w0, w1, start = _bank(p)
     F, M = fb.shape
     T = 4
@@ -144,7 +149,7 @@ def test_wave_formulation_tracks_the_oracle():
                 q = (f32(2) * (Q[:, 0] + Q[:, 1]).astype(f32) + S[:, 1]).astype(f32)
                 s = (S[:, 0] + S[:, 1]).astype(f32)
                 a = (A0[c][:, 1] * q + (A0[c][:, 0] * s).astype(f32)).astype(f32)
-                b = (s - a).astype(f32) if c >= 4 else (A1[c][:, 1] * q + (A1[c][:, 0] * s).astype(f32)).astype(f32)
+                b = (s - a).astype(f32) if uf and c >= 4 else (A1[c][:, 1] * q + (A1[c][:, 0] * s).astype(f32)).astype(f32)
                 A.append(a)
                 B.append(b)
             d0 = []
@@ -158,7 +163,7 @@ def test_wave_formulation_tracks_the_oracle():
                 old = n0[c + 1] if c < 7 else zero
                 n1.append(_shift_from_prev(old, n0[c]) if c & 1 else _shift_from_next(old, n0[c]))
             for c in range(8):
-                if c >= 4:
+                if uf and c >= 4:
                     dd = (n0[c] - n1[c]).astype(f32)
                     cc = (dd * A0[c][:, 0] + n1[c]).astype(f32)
                     st = (dd * A0[c][:, 1]).astype(f32)
@@ -183,5 +188,5 @@ def test_wave_formulation_tracks_the_oracle():
                 out[start[G[c][l]]:start[G[c][l]] + n[l], t] = x[c][l, :n[l]] / SC
                 assert not x[c][l, n[l]:].any()  # padding slots stayed at exactly zero through every step
     rel = float(np.linalg.norm(out[act] - ref[act]) / np.linalg.norm(ref[act]))
-    print(f"wave formulation: rel-L2 {rel:.2e} vs the oracle after {p.max_mel_iters} steps")
+    print(f"wave formulation, mel_scale_norm={norm!r}: rel-L2 {rel:.2e} vs the oracle after {p.max_mel_iters} steps")
     assert rel <= 2e-6
