@@ -58,6 +58,24 @@ def group_of(c, lane):
     return 64 * c + 63 - lane if c & 1 else 64 * c + lane
 
 
+def test_constants_match_the_header_and_the_dealing_is_a_bijection():
+    import re
+
+    hdr = open(os.path.join(ROOT, "riffusion-hobby_amd", "csrc", "rfx_kernels.h")).read()
+    pairs = tuple(int(x) for x in re.search(r"kImelWavePairs\[kImelWaveChunks\] = \{([^}]*)\}", hdr).group(1).split(","))
+    full = tuple(int(x) for x in re.search(r"kImelWaveFullPairs\[kImelWaveChunks\] = \{([^}]*)\}", hdr).group(1).split(","))
+    assert pairs == PAIRS and full == FULL and all(f < p for f, p in zip(full, pairs))
+    assert "return (chunk & 1) ? 64 * chunk + 63 - lane : 64 * chunk + lane;" in hdr  # group_of() below
+    seen = sorted(group_of(c, lane) for c in range(8) for lane in range(64))
+    assert seen == list(range(512))
+    for c in range(7):  # where two chunks meet, the neighbouring groups sit in the SAME lane (the DPP shift's `old` operand)
+        end = 63 if c % 2 == 0 else 0
+        assert group_of(c + 1, end) == group_of(c, end) + 1
+    for c in range(8):  # inside a chunk the successor is the next lane (even chunks) or the previous one (odd chunks)
+        for lane in range(63):
+            assert group_of(c, lane + 1) - group_of(c, lane) == (-1 if c & 1 else 1)
+
+
 def test_default_bank_fits_the_chunk_budgets_and_its_weights_are_lines():
     p = O.OracleParams()
     fb, act, w0, w1, start = _bank(p)
