@@ -451,3 +451,21 @@ def test_plan_options_are_validated_before_any_device_call(repo_root):
     for kw in ({"gl_form": "sometimes"}, {"frame_engine": "fastest"}, {"plan_layout": "dense"}, {"imel_form": "fast"}):
         with pytest.raises(ValueError):
             _hip.Plan(SpectrogramParams(sample_rate=48000), "cpu", **kw)
+
+
+def test_c_abi_refuses_bad_plan_options_before_any_device_call(repo_root):
+    """rfx_plan_create_ex validates rfx_plan_options first (no GPU needed to get the refusal): an imel_form / plan_layout outside
+    the enums and a struct_size larger than the library's own struct are RFX_ERR_INVALID with a message that names the field."""
+    import ctypes
+
+    from riffusion import _hip
+
+    lib = _hip.load_library()
+    win = (ctypes.c_float * 4410)()
+    cp = _hip.RfxParams(44100, 17640, 4410, 441, 512, 200)
+    handle = ctypes.c_void_p()
+    size = ctypes.sizeof(_hip.RfxPlanOptions)
+    for opt, word in ((_hip.RfxPlanOptions(size, 0, 0, 0, 0, 7), b"imel_form"), (_hip.RfxPlanOptions(size, 0, 0, 0, 5, 0), b"plan_layout"),
+                      (_hip.RfxPlanOptions(size + 4, 0, 0, 0, 0, 0), b"struct_size"), (_hip.RfxPlanOptions(4, 0, 0, 0, 0, 0), b"struct_size")):
+        rc = lib.rfx_plan_create_ex(ctypes.byref(cp), ctypes.cast(win, ctypes.c_void_p), None, 0, ctypes.byref(opt), ctypes.byref(handle))
+        assert rc != 0 and not handle.value and word in lib.rfx_last_error(), (rc, lib.rfx_last_error())
