@@ -26,6 +26,10 @@ Extra objects on the JSON line:
                  divided by the launch duration measured with HIP events on the launch stream.
   cpu_baseline - the CPU oracle (oracle/riffusion_oracle.py, a torch-CPU port of the reference's
                  torchaudio path) timed on this host on ONE tile of the same workload.
+  other_configs - `stereo64`: one GPU's share of BASELINE.json configs[3] (64 stereo clips, Griffin-Lim 64) through the product entry
+                 point with its own canonical-bytes roofline; `batch_sweep`: the decode step at B = 16 ... 128 (the run partition of
+                 rfx_griffinlim keeps every resident workgroup slot busy whatever B is).  After the timed region; context only.
+  ms_per_step_min / median / max, shader_clock - the K timed steps one by one and the sclk the chip held meanwhile.
   other_sample_rates - the same decode step, and the forward path, at 48 kHz (n_fft 19200 / win 4800 / hop 480) and
                  22.05 kHz (8820 / 2205 / 220): the row-family kernels of csrc/rfx_fam.hip, measured after the
                  timed region; context only.
@@ -62,6 +66,7 @@ def parse():
     ap.add_argument("--global-clips", type=int, default=512, help="decode-stereo64: clips in the sharded batch")
     ap.add_argument("--no-forward", action="store_true", help="skip the embedded configs[2] forward measurement")
     ap.add_argument("--no-other-rates", action="store_true", help="skip the embedded 48 kHz decode measurement (row-family Griffin-Lim engine)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the embedded configs[3] share (64 stereo clips, Griffin-Lim 64) and the batch-shape sweep")
     ap.add_argument("--host-input", action="store_true",
                     help="decode-stereo64: the timed calls take the tiles from HOST memory (the reference's API is host images in, host "
                          "audio out); uploads run chunk by chunk through pinned memory on a side stream (batch_shard.ChunkSource)")
@@ -177,6 +182,75 @@ def valu_binding(valu_instr_per_launch: float, launch_ms: float, mix: dict, pmc:
         out["measured_ns_per_valu_instruction"] = round(ns_per_instr, 3)
         out["frac_of_measured_instruction_rate"] = round(valu_instr_per_launch / 1024.0 * ns_per_instr * 1e-6 / launch_ms, 4)
     return out
+
+
+class ClockSampler:
+    """Shader clock the chip sustains DURING the timed region: a host thread reads the driver's current-sclk file every few
+    milliseconds while the steps run (no device work, no sync).  The kernels of this path are VALU-bound and the chip clocks down
+    to its power budget under them (1.93 - 2.06 GHz depending on the box), which is most of the box-to-box spread
+    of `value`.  Reports nothing (source: null) where the driver exposes no such file."""
+
+    def __init__(self, index: int):
+        import glob
+        import threading
+
+        self.samples, self.path, self.kind = [], None, None
+        self._stop = threading.Event()
+        self._thread = None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cards:
+            self.path, self.kind = cards[min(index or 0, len(cards) - 1)], "pp_dpm_sclk"
+
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                for line in f:
+                    if line.rstrip().endswith("*"):
+                        return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(0.004)
+
+    def start(self):
+        import threading
+
+        if self.path:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return {"source": None, "note": "no current-sclk file readable on this host"}
+        xs = sorted(self.samples)
+        return {"source": self.kind, "samples": len(xs), "mhz_min": xs[0], "mhz_median": xs[len(xs) // 2], "mhz_max": xs[-1],
+                "note": "current sclk level of the driver, polled by a host thread during the timed steps"}
+
+
+def kernel_source_fingerprint(files=("rfx_gl.hip", "rfx_core.h", "rfx_frame.hip.h")) -> str:
+    """sha1 over the sources the dominant kernel is compiled from (the GPU box and the driver's checkout have no .git): the PMC
+    summaries carry the fingerprint of the sources they were collected on, and a line whose sources differ says `stale`."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for name in files:
+        try:
+            with open(os.path.join(ROOT, "riffusion-hobby_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            h.update(b"?")
+    return h.hexdigest()[:12]
 
 
 def cpu_baseline(iters: int, threads_cap: int = 16, min_seconds: float = 10.0, max_tiles: int = 8):
@@ -348,6 +422,9 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
                         "neither HBM nor the MFMA pipes bound this kernel: `frac` (HBM) is small by construction, true_flops_frac prices the "
                         "flops actually executed against the 157.3 TFLOP/s fp32 peak, and `binding` (occupancy of the fp32 VALU pipes) is the resource that bounds it; "
                         "avg_launch_ms is one launch between two stream drains (HIP events)"}
+        fp_here = kernel_source_fingerprint(("rfx_stft.hip", "rfx_core.h", "rfx_frame.hip.h"))
+        roof["from_profiles"] = {"source": pmc_src, "git": profile_rev(fpmc, pmc_src) if fpmc else None, "kernel_sources_of_summary": fpmc.get("src_sha"),
+                                 "kernel_sources_here": fp_here, "stale": fpmc.get("src_sha") != fp_here}
         valu = fpmc.get("SQ_INSTS_VALU_per_launch")
         if valu:
             b = valu_binding(valu * fscale, mel_ms, isa_mix("rfx::stft_mel2_kernel"), fpmc, pmc_src, profile_rev(fpmc, pmc_src))
@@ -571,17 +648,25 @@ def main():
 
     for w in range(args.warmup):
         step(w)
+    clock = ClockSampler(dev.index)
+    # one event per step on the launch stream (no host sync inside the timed region): the spread of the K steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
+    clock.start()
     t0 = time.perf_counter()
+    marks[0].record()
     for k in range(args.steps):
         pcm = step(100 + k)
+        marks[k + 1].record()
     sync_all()
     elapsed = time.perf_counter() - t0
+    clock.stop()
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(pcm.float()).all())
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     # ---- roofline leg (outside the timed region): per-launch durations from HIP events on the stream
     roofline = None
@@ -615,7 +700,10 @@ def main():
             # counters cannot be collected from inside the timed process: these fields are read from the committed
             # rocprofv3 --pmc summary of the same kernel (re-collected whenever the kernel changes)
             "from_profiles": {"fields": ["traffic", "actual_hbm_gbs", "actual_hbm_frac", "binding.valu_wave_instructions_per_launch", "binding.measured_clock_ghz"],
-                              "source": pmc_src, "git": profile_rev(pmc, pmc_src)},
+                              "source": pmc_src, "git": profile_rev(pmc, pmc_src),
+                              # the summary names the kernel sources it was collected on; `stale` = this checkout's differ
+                              "kernel_sources_of_summary": pmc.get("src_sha"), "kernel_sources_here": kernel_source_fingerprint(),
+                              "stale": pmc.get("src_sha") != kernel_source_fingerprint()},
             # `achieved` prices the kernel against the CANONICAL fused formulation of SURVEY 8(d) (|S| 4 B + tprev
             # 8 B read + 8 B written per bin and iteration: an HBM-bound kernel).  The shipped kernel applies the
             # momentum in the time domain (STFT linearity), streams only |S| (`traffic` is what it really moves)
@@ -631,6 +719,11 @@ def main():
             b = valu_binding(valu, avg_ms, isa_mix("rfx::gl_iter_kernel<2>"), pmc, pmc_src, profile_rev(pmc, pmc_src))
             if b:
                 roofline["binding"] = b
+        # the three readings side by side: `frac` prices the canonical 20 B per bin and iteration of SURVEY 8(d) (bytes the shipped
+        # formulation does not move), `actual_hbm_frac` what it really streams, `binding_frac` the fp32 pipes that bound it
+        roofline["summary"] = {"frac_canonical_bytes": roofline["frac"], "actual_hbm_frac": roofline.get("actual_hbm_frac"),
+                               "binding_frac_valu_pipe": (roofline.get("binding") or {}).get("frac"),
+                               "binding_frac_of_measured_instruction_rate": (roofline.get("binding") or {}).get("frac_of_measured_instruction_rate")}
         # stage split of one step (events through torch on the current stream = the launch stream)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         evs[0].record()
@@ -659,6 +752,13 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
+            # the K timed steps one by one (an event per step on the launch stream, rank 0): boxes of the pool differ by a few per
+            # cent (the chip settles at 1.9 - 2.1 GHz under this load), steps on one box by far less - a regression smaller than the
+            # spread between boxes shows up here, not in `value`
+            "ms_per_step_min": round(per_step[0], 3),
+            "ms_per_step_median": round(per_step[len(per_step) // 2], 3),
+            "ms_per_step_max": round(per_step[-1], 3),
+            "shader_clock": clock.summary(),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -740,6 +840,58 @@ def main():
                                 "n_fft": p2.n_fft, "hop_length": p2.hop_length, "finite": bool(torch.isfinite(pcm2.float()).all()),
                                 "workload": f"batch={B} synthetic 512x512 mono uint8 tiles -> audio at {rate} Hz, Griffin-Lim {args.iters}"}
 
+    # ---- BASELINE.json configs[3], one GPU's share: 64 stereo clips (128 tile-channels), Griffin-Lim 64, through the product
+    # entry point (uint8 tiles resident in HBM -> int16 PCM on the device), and the decode step over batch shapes that do not
+    # divide the chip's 512 resident Griffin-Lim workgroups (cli.py:172-204 feeds arbitrary file counts per batch)
+    other_cfg = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        from riffusion.spectrogram_image_converter import SpectrogramImageConverter as _SIC
+
+        other_cfg = {}
+        conv64 = _SIC(SpectrogramParams(stereo=True, num_griffin_lim_iters=64), device=str(dev))
+        tiles64 = torch.from_numpy(np.random.default_rng(7).integers(0, 256, size=(64, N_MELS, T, 3), dtype=np.uint8)).to(dev)
+        conv64.audio_from_spectrogram_images(tiles64, seed=0, return_device=True)
+        torch.cuda.synchronize(dev)
+        n64 = 3
+        t64 = time.perf_counter()
+        for k in range(n64):
+            pcm64 = conv64.audio_from_spectrogram_images(tiles64, seed=1 + k, return_device=True)
+        torch.cuda.synchronize(dev)
+        dt64 = (time.perf_counter() - t64) / n64
+        alg64 = 64 * 2 * (20.0 * 64 + 4) * N_BINS * T  # (20 n + 4) F T per tile-channel = 11.60 GB per stereo tile at n = 64
+        other_cfg["stereo64"] = {
+            "metric": "stereo_spectrogram_tiles_per_sec_griffinlim64", "value": round(64 / dt64, 2), "unit": "tiles/s", "ms_per_step": round(dt64 * 1e3, 3),
+            "steps": n64, "finite": bool(torch.isfinite(pcm64.float()).all()),
+            "workload": "64 synthetic stereo 512x512 uint8 tiles (128 tile-channels; one GPU's share of BASELINE.json configs[3]: 512 stereo tiles over "
+                        "8 GPUs) -> SpectrogramImageConverter.audio_from_spectrogram_images -> int16 PCM, Griffin-Lim 64; tiles and PCM resident in HBM",
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": alg64, "achieved": round(alg64 / dt64 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg64 / dt64 / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "canonical bytes of SURVEY 8(d) for the WHOLE step (InverseMelScale and the codecs included in the time, not in the bytes)"}}
+        sweep = {}
+        for Bs in (16, 48, 64, 65, 96, 100, 128):
+            tl = torch.from_numpy(np.random.default_rng(Bs).integers(0, 256, size=(Bs, N_MELS, T, 3), dtype=np.uint8)).to(dev)
+            ws = torch.empty(plan.lib.rfx_griffinlim_workspace_bytes(plan.handle, Bs, T), dtype=torch.uint8, device=dev)
+
+            def step_b(seed):
+                m_ = plan.image_decode(tl, False, lut)
+                l_ = plan.inverse_mel(m_, 1, seed=seed)
+                w_ = plan.griffinlim(l_, Bs, T, args.iters, 0.99, seed=seed + 1, workspace=ws)
+                return plan.pcm16(w_, channels=1, normalize=True)[0]
+
+            step_b(0)
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter()
+            for k in range(3):
+                step_b(5 + k)
+            torch.cuda.synchronize(dev)
+            dtb = (time.perf_counter() - tb) / 3
+            sweep[str(Bs)] = {"tiles_per_s": round(Bs / dtb, 1), "ms_per_step": round(dtb * 1e3, 3)}
+            del tl, ws
+        for Bs in (65, 96, 100):  # distance from the straight line between B = 64 and B = 128 (the run partition has no cliff: <= 5 %)
+            line = sweep["64"]["ms_per_step"] + (sweep["128"]["ms_per_step"] - sweep["64"]["ms_per_step"]) * (Bs - 64) / 64.0
+            sweep[str(Bs)]["vs_linear_64_128_pct"] = round(100.0 * (sweep[str(Bs)]["ms_per_step"] / line - 1.0), 2)
+        other_cfg["batch_sweep"] = {"workload": f"the headline decode step (Griffin-Lim {args.iters}) at other batch sizes, 3 steps each", "by_batch": sweep}
+
     # ---- configs[2] (audio -> mel image) measured in the same run and carried on the same line
     fwd = None
     if not args.no_forward:
@@ -748,6 +900,8 @@ def main():
         out["single_tile_latency"] = latency
         if other is not None:
             out["other_sample_rates"] = other
+        if other_cfg is not None:
+            out["other_configs"] = other_cfg
         if fwd is not None:
             out["forward"] = {k: fwd[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "stages")}
         if world == 1 and not args.no_cpu_baseline:

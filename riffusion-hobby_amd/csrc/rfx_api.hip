@@ -994,6 +994,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
                            void* stream_, float* h_launch_ms) {
   if (!plan || !d_mag_slots || !d_wave_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_griffinlim: null argument");
   if (B <= 0 || T < 2 || n_iter < 0) return fail(RFX_ERR_INVALID, "rfx_griffinlim: bad shape");
+  if ((long long)B * T > 0x7fffffffLL) return fail(RFX_ERR_INVALID, "rfx_griffinlim: more than 2^31 - 1 frames in one call");
   if (!(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_griffinlim: momentum must be in [0, 1)");
   if (plan->generic) {
     RFX_ON_DEVICE(plan->device);
@@ -1074,14 +1075,15 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   g.mom = momentum / (1.f + momentum);
   g.seed = seed;
   g.timing = plan->timing;
-  // runs: fill every resident workgroup slot of the chip once; every run at least 10 frames long so
-  // that a hop block is shared by at most two runs
-  const int slots = plan->num_cus * plan->gl_wgs_per_cu;
-  int nruns = (slots + B - 1) / B;
-  if (nruns > T / 10) nruns = T / 10;
+  // runs: the batch's B*T frames, counted clip after clip, are cut into equal runs (+- 1 frame), one per resident workgroup slot
+  // of the chip and never more (a launch of 520 workgroups on 512 slots runs eight of them alone in a second wave: the
+  // ceil(slots / B) runs per clip of rounds 1-4 did that for every B that does not divide the slot count); every run at least
+  // 10 frames long, so that a hop block is shared by at most two runs.  At B = 64, T = 512 this is the old partition exactly.
+  const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu;
+  long long nruns = ((long long)B * T) / 10;
+  if (nruns > slots) nruns = slots;
   if (nruns < 1) nruns = 1;
-  g.nruns = nruns;
-  const int nblocks = B * nruns;
+  const int nblocks = (int)nruns;
 
   // optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg)
   EventList events;

@@ -69,16 +69,41 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   const ThreadId t = thread_id();
   const FrameCtx f = frame_ctx(smem, t, g.tw1, g.tw2);
 
-  const int clip = blockIdx.x / g.nruns;
-  const int run = blockIdx.x - clip * g.nruns;
-  const int t0 = (int)(((long long)run * g.T) / g.nruns);
-  const int t1 = (int)(((long long)(run + 1) * g.T) / g.nruns) - 1;
-  const int par = run & 1;
+  // Run r of the launch's gridDim.x runs owns the frames [r N / R, (r + 1) N / R) of the batch's N = B T frames, counted clip
+  // after clip: every resident workgroup slot gets the same number of frames (+- 1) WHATEVER the batch size is (the host keeps
+  // R <= slots and every run at least 10 frames long).  A run that crosses a clip boundary is walked as one SEGMENT per clip;
+  // the segments of a clip belong to consecutive runs, so the two runs that share a hop block always differ in parity.
+  // (Until round 5 every clip was cut into ceil(slots / B) runs of its own: B = 65 launched 520 workgroups for 512 slots.)
+  const long long nfr_all = (long long)g.B * g.T;  // < 2^31 (checked by the host)
+  const int gf_end = (int)(((long long)(blockIdx.x + 1) * nfr_all) / gridDim.x);
+  int gf = (int)(((long long)blockIdx.x * nfr_all) / gridDim.x);
+  const int par = blockIdx.x & 1;
   const int nblk = g.T - 1;  // hop blocks kept by istft's centre trim
 
   const size_t clip_slots = (size_t)g.T * kFrameStride;
-  const rsrc_t Ssrc = make_rsrc(g.S + clip * clip_slots, clip_slots * sizeof(float));
   const bool have_init = g.angles0 != nullptr;
+  const rsrc_t scl = make_rsrc(g.out_scale, (size_t)g.L * 4);
+  const rsrc_t win = make_rsrc(g.win, kWin * 4);
+  const unsigned npr4 = (unsigned)t.npr * 4u;
+  const unsigned q16 = (unsigned)slot_qp(t.npr) * 16u;  // byte offset of this thread's 16-B slot groups in the streams
+  __syncthreads();  // tw2 table in LDS
+  Tw1 tw1;  // g(n')^k1 of this thread: fetched in the synthesis half, reused by the next frame's analysis
+  if (MODE != 0) load_tw1(tw1, f);
+  // the thread's ten Hann samples w[441 j + n']: fetched with the twiddles (in flight across the synthesis
+  // barrier), used by the overlap-add and by the next frame's analysis
+  float wv[10];
+  auto load_window = [&] {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) wv[j] = ld1(win, npr4, (unsigned)j * (kHop * 4u));
+  };
+  if (MODE != 0) load_window();
+
+  while (gf < gf_end) {
+  const int clip = gf / g.T;
+  const int t0 = gf - clip * g.T;
+  const int t1 = min(g.T - 1, t0 + (gf_end - gf) - 1);
+  gf += t1 - t0 + 1;
+  const rsrc_t Ssrc = make_rsrc(g.S + clip * clip_slots, clip_slots * sizeof(float));
   const rsrc_t init = make_rsrc(have_init ? (const void*)(g.angles0 + clip * clip_slots) : (const void*)g.S,
                                 clip_slots * sizeof(cf));
   const rsrc_t in0 = make_rsrc(g.audio_in[0] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
@@ -87,10 +112,6 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   const rsrc_t pv1 = make_rsrc(g.audio_prev[1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t outA = make_rsrc(g.audio_out[par] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t outB = make_rsrc(g.audio_out[par ^ 1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
-  const rsrc_t scl = make_rsrc(g.out_scale, (size_t)g.L * 4);
-  const rsrc_t win = make_rsrc(g.win, kWin * 4);
-  const unsigned npr4 = (unsigned)t.npr * 4u;
-  const unsigned q16 = (unsigned)slot_qp(t.npr) * 16u;  // byte offset of this thread's 16-B slot groups in the streams
 
   float acc[10];
 #pragma unroll
@@ -144,7 +165,6 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   // LDS/VALU stretch follows; its normalisation factor is fetched across the synthesis barrier.
   float pend_val = 0.f, pend_scale = 0.f;
   int pend_blk = -1;
-  __syncthreads();  // tw2 table in LDS
 
 #ifdef RFX_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -153,16 +173,6 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #else
 #define RFX_STAMP(i) ((void)0)
 #endif
-  Tw1 tw1;  // g(n')^k1 of this thread: fetched in the synthesis half, reused by the next frame's analysis
-  if (MODE != 0) load_tw1(tw1, f);
-  // the thread's ten Hann samples w[441 j + n']: fetched with the twiddles (in flight across the synthesis
-  // barrier), used by the overlap-add and by the next frame's analysis
-  float wv[10];
-  auto load_window = [&] {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) wv[j] = ld1(win, npr4, (unsigned)j * (kHop * 4u));
-  };
-  if (MODE != 0) load_window();
   for (int fr = t0; fr <= t1; ++fr) {
     const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
     const unsigned rng_key = rand_frame_key(g.seed, (unsigned long long)clip * g.T + fr);
@@ -282,10 +292,11 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
     for (int i = 0; i < 12; ++i) g.timing[((size_t)blockIdx.x * kWaves + w) * 12 + i] = tacc[i];
   }
 #endif
-  // ---- flush the parked block and the right halo of the run
+  // ---- flush the parked block and the right halo of the segment
   emit_scaled(pend_blk, pend_val);
 #pragma unroll
   for (int j = 0; j < 9; ++j) emit(t1 - 4 + j, acc[j]);
+  }  // next segment of the run (another clip)
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ struct GlArgs {
   const cf* tw1;              // [21][441]
   const cf* tw2;              // [21][21]
   const float* win;           // [4410]
-  int B, T, L, Lpad, nruns;
+  int B, T, L, Lpad;          // (the runs of a launch are its workgroups: gridDim.x)
   float mom;                  // momentum / (1 + momentum)
   unsigned long long seed;
   unsigned long long* timing;  // optional [nblocks][8] phase timers (RFX_TIMING builds only)

@@ -46,6 +46,17 @@ def test_headline_line_small_batch():
     assert o["griffinlim_engine"] == "row-family" and o["n_fft"] == 19200 and o["tiles_per_s"] > 0 and o["finite"] is True
     o2 = d["other_sample_rates"]["22050"]
     assert o2["griffinlim_engine"] == "row-family" and o2["n_fft"] == 8820 and o2["tiles_per_s"] > 0 and o2["forward_images_per_s"] > 0
+    # round 5: the spread of the timed steps and the clock, the three roofline readings by name, provenance of the counters,
+    # configs[3]'s one-GPU share and the batch-shape sweep on the same line
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"] and "source" in d["shader_clock"]
+    assert set(r["summary"]) == {"frac_canonical_bytes", "actual_hbm_frac", "binding_frac_valu_pipe", "binding_frac_of_measured_instruction_rate"}
+    assert isinstance(r["from_profiles"]["stale"], bool) and len(r["from_profiles"]["kernel_sources_here"]) == 12
+    s64 = d["other_configs"]["stereo64"]
+    assert s64["unit"] == "tiles/s" and s64["value"] > 0 and s64["finite"] is True and 0 < s64["roofline"]["frac"] < 1.5
+    sweep = d["other_configs"]["batch_sweep"]["by_batch"]
+    assert set(sweep) == {"16", "48", "64", "65", "96", "100", "128"}
+    for b_ in ("65", "96", "100"):  # no run-partition cliff: within 5 % of the straight line between B = 64 and B = 128
+        assert abs(sweep[b_]["vs_linear_64_128_pct"]) <= 5.0, sweep
 
 
 def test_distributed_launch_one_rank_keeps_stdout_clean():

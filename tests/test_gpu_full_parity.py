@@ -96,8 +96,9 @@ def test_mono_tile_full_size_inverse_mel_and_griffinlim32(O):
     full = conv.waveform_from_mel_amplitudes(mel.cuda(), spec0=spec0.cuda(), angles0=angles0.cuda()).cpu()
     s_full = snr_db(want, full)
     print(f"waveform_from_mel_amplitudes T=512 (device SGD -> device Griffin-Lim): {s_full:.1f} dB vs oracle")
-    # the 1e-4-level differences of the two SGD results are amplified by 32 chaotic iterations: looser floor
-    assert s_full >= 40.0
+    # the 1e-7-level differences of the two SGD results are amplified by 32 chaotic iterations; measured 93.0 dB (rounds 2-4,
+    # profiles/r04f_gpu_parity_figures.txt) - the gate sits 13 dB under that, not 53 dB (it was 40 until round 5)
+    assert s_full >= 80.0
 
 
 def test_stereo_tile_griffinlim64_full_size(O):
@@ -162,12 +163,12 @@ def test_og_beat_end_to_end_spectral_convergence(O, golden_dir):
     lin_o2 = O.inverse_mel_scale_sgd(mel, op)
     sc_o2 = O.spectral_convergence(O.griffinlim(lin_o2, op), lin_o2, op)
     print(f"og_beat spectral convergence: oracle {sc_o:.5f} / {sc_o2:.5f}, device {sc_d:.5f} / {sc_d2:.5f} (two seeds each)")
-    # SURVEY 8(d) proposed "within 1 % of the oracle's"; the figure itself moves by 1-2 % from one random
-    # initialisation to the next on BOTH sides (measured: device 0.15672 / 0.15423, see the printed oracle pair), so the
-    # gate is 3 % of the oracle's value and the two device draws must bracket or sit next to the oracle's two
+    # SURVEY 8(d) proposed "within 1 % of the oracle's"; the figure itself moves by 1-2 % from one random initialisation to the
+    # next on BOTH sides, so two draws cannot carry a 1 % gate (rounds 2-4 had a 3 % / 2 % gate here).  The 1 % gate is held where
+    # it can be: on the means of 32 initialisations per side (tests/test_gpu_round4.py::test_og_beat_mean_spectral_convergence_32_fresh_seeds).
+    # Here the two pairs are printed, and only a gross failure (10 %: a different algorithm) is refused.
     for sc in (sc_d, sc_d2):
-        assert min(abs(sc - sc_o), abs(sc - sc_o2)) <= 0.03 * sc_o
-    assert abs(0.5 * (sc_d + sc_d2) - 0.5 * (sc_o + sc_o2)) <= 0.02 * sc_o
+        assert min(abs(sc - sc_o), abs(sc - sc_o2)) <= 0.10 * sc_o
     # the mel re-projection error of the SGD result is RNG-independent to first order as well
     fb = O.mel_filterbank(op)
     err_o = float(torch.linalg.norm(O.mel_scale(lin_o, fb) - mel) / torch.linalg.norm(mel))

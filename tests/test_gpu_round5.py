@@ -1,0 +1,87 @@
+"""
+Round 5: the Griffin-Lim run partition.  rfx_griffinlim cuts the batch's B x T frames, counted clip after clip, into equal runs -
+one per resident workgroup slot, never more - so a run may cross a clip boundary (csrc/rfx_gl.hip: one segment per clip).  Until
+round 5 every clip had ceil(slots / B) runs of its own and B = 65 or 100 launched more workgroups than the chip holds.
+Everything goes through the C ABI; the oracle is the checker.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import snr_db
+
+pytestmark = pytest.mark.gpu
+
+T = 512
+
+
+@pytest.fixture(scope="module")
+def plan():
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    return _hip.get_plan(SpectrogramParams(), "cuda")
+
+
+@pytest.fixture(scope="module")
+def O():
+    import riffusion_oracle
+
+    return riffusion_oracle
+
+
+@pytest.mark.parametrize("B", [65, 100])
+def test_batches_that_do_not_divide_the_slots_equal_the_64_tile_partition(plan, O, B):
+    """cli.py:172-204 hands over whatever number of files a directory holds.  B = 65 / 100 at the headline tile size: every clip
+    must come out as it does inside a batch of 64 (the partition rounds 1-4 measured and tested: 64-frame runs that never cross
+    a clip) up to the summation order at the run seams, and one clip of the odd-sized batch is checked against the oracle."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(500 + B)
+    S = torch.rand(B * T, plan.frame_stride, device=dev, generator=g) * 1000.0
+    mag = plan.unpack_magnitudes(S, B, T)          # what the slots mean as (B, n_stft, T) ...
+    S = plan.pack_magnitudes(mag)                  # ... with duplicate slots consistent
+    a0_bft = torch.view_as_complex(torch.rand(B, plan.n_stft, T, 2, device=dev, generator=g))
+    A = plan.pack_complex(a0_bft)
+    assert plan.lib.rfx_griffinlim_form(plan.handle, B, T) == 1  # the run-based kernel
+    whole = plan.griffinlim(S, B, T, 3, 0.99, angles0_slots=A)
+    assert whole.shape == (B, 441 * (T - 1)) and bool(torch.isfinite(whole).all())
+    worst = 1e9
+    for lo in range(0, B, 64):
+        hi = min(B, lo + 64)
+        n = hi - lo
+        if n < 64:  # pad the last chunk to 64 clips so that it, too, takes the 64-frame runs of the old partition
+            idx = torch.arange(lo, lo + 64, device=dev) % B
+        else:
+            idx = torch.arange(lo, hi, device=dev)
+        rows = (idx[:, None] * T + torch.arange(T, device=dev)[None, :]).reshape(-1)
+        part = plan.griffinlim(S[rows].contiguous(), 64, T, 3, 0.99, angles0_slots=A[rows].contiguous())
+        for i in range(n):
+            worst = min(worst, snr_db(part[i], whole[lo + i]))
+    print(f"B = {B}: every clip vs the same clip inside a 64-tile batch after 3 iterations: worst {worst:.1f} dB")
+    assert worst >= 105.0
+    b = B - 1  # the last clip: its runs start in the clip before it
+    want = O.griffinlim(mag[b : b + 1].cpu(), O.OracleParams(), angles0=a0_bft[b : b + 1].cpu(), n_iter=3)
+    s = snr_db(want, whole[b : b + 1].cpu())
+    print(f"B = {B}: clip {b} vs the oracle after 3 iterations: {s:.1f} dB")
+    assert s >= 95.0
+
+
+@pytest.mark.parametrize("B,Tn", [(100, 60), (37, 150), (9, 57), (523, 22)])
+def test_runs_that_cross_clip_boundaries_against_the_oracle(plan, O, B, Tn):
+    """Short clips, many of them: runs of ~12 frames cut through clips of 22 - 150 frames, most runs hold parts of two clips and
+    some clips are shared by three runs.  All clips against the oracle (injected initial angles, 3 iterations)."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    pl = _hip.get_plan(SpectrogramParams(), "cuda", gl_form="runs")
+    op = O.OracleParams()
+    g = torch.Generator().manual_seed(31 * B + Tn)
+    mag = torch.rand(B, op.n_stft, Tn, generator=g) * 1000.0
+    a0 = torch.rand(B, op.n_stft, Tn, dtype=torch.complex64, generator=g)
+    want = O.griffinlim(mag, op, angles0=a0, n_iter=3)
+    got = pl.griffinlim(pl.pack_magnitudes(mag.cuda()), B, Tn, 3, 0.99, angles0_slots=pl.pack_complex(a0.cuda())).cpu()
+    per_clip = [snr_db(want[i], got[i]) for i in range(B)]
+    print(f"B = {B}, T = {Tn}: Griffin-Lim 3 vs oracle: all clips {snr_db(want, got):.1f} dB, worst clip {min(per_clip):.1f} dB")
+    # a seam handled wrongly leaves a clip at 10 - 30 dB; one ill-conditioned bin (tests/helpers.py::mask_ill_conditioned_bins) can
+    # cost a 22-frame clip up to 10 log10(F T / 12) = 42 dB, so the per-clip floor is 45 dB and the tight gates are the batch and the median
+    assert got.shape == want.shape and snr_db(want, got) >= 95.0 and float(np.median(per_clip)) >= 100.0 and min(per_clip) >= 45.0

@@ -77,7 +77,9 @@ def test_griffinlim_injected_init_snr(plan, oparams, n_iter, floor_db):
 
 
 def test_griffinlim_many_runs_equals_single_run(plan, oparams):
-    """B=1 is split over many frame runs (halo path); B large gives one run per clip: same answer."""
+    """B=1 is split over many frame runs (halo path); B large gives long runs that cross clip boundaries (round 5: the batch's
+    frames are cut into equal runs whatever B is, so identical clips at different places of a batch are cut at different
+    frames and agree to summation order at the seams, not bit for bit): same answer."""
     import riffusion_oracle as O
 
     T = 120
@@ -93,7 +95,10 @@ def test_griffinlim_many_runs_equals_single_run(plan, oparams):
     An = A1.repeat(reps, 1)
     many = plan.griffinlim(Sn, reps, T, 3, 0.99, angles0_slots=An).cpu()
     assert snr_db(many[0:1], one) > 110.0
-    assert torch.equal(many[0], many[reps - 1])
+    for i in (1, 137, reps - 1):
+        assert snr_db(many[0:1], many[i:i + 1]) > 110.0
+    again = plan.griffinlim(Sn, reps, T, 3, 0.99, angles0_slots=An).cpu()
+    assert torch.equal(many, again)  # the same launch twice: the same bits (no atomics at the run seams)
     ref = O.griffinlim(mag, oparams, angles0=angles0, n_iter=3)
     assert snr_db(ref, one) > 95.0
 

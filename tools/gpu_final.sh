@@ -16,6 +16,6 @@ print({k: (v.get("tiles_per_s"), v.get("forward_images_per_s"), v.get("griffinli
 print(d["roofline"].get("binding", {}).get("frac_of_measured_instruction_rate"), d["cpu_baseline"])
 PY
 cd /tmp && export TMPDIR=/tmp
-timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/stats.log 2>&1
 cp $OUT/stats/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null; head -6 $OUT/kernel_stats.csv | cut -c1-160
 cd $R; [ -n "$NO_PMC" ] || { bash tools/pmc_imel.sh > $OUT/pmc_imel.log 2>&1; tail -1 $OUT/pmc_imel.log | cut -c1-400; }

@@ -24,11 +24,19 @@ def loop_mix(asm: str, symbol: str):
     s = asm.index(symbol + ":")
     body = asm[s:asm.index("s_endpgm", s)].split("\n")
     labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
-    best = None
-    for i, l in enumerate(body):  # the frame loop: the longest backward branch
+    loops = []
+    for i, l in enumerate(body):
         m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i and (best is None or i - labels[m.group(1)] > best[1] - best[0]):
-            best = (labels[m.group(1)], i)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append((labels[m.group(1)], i))
+    # the frame loop: the longest backward branch - or, when that one is an outer loop around it (round 5: gl_iter_kernel walks the
+    # segments of a run), the loop nested inside it that makes up most of its body
+    best = max(loops, key=lambda ab: ab[1] - ab[0])
+    while True:
+        inner = [ab for ab in loops if best[0] <= ab[0] and ab[1] <= best[1] and ab != best and 2 * (ab[1] - ab[0]) >= best[1] - best[0]]
+        if not inner:
+            break
+        best = max(inner, key=lambda ab: ab[1] - ab[0])
     mix = collections.Counter()
     for l in body[best[0]:best[1] + 1]:
         m = re.match(r"\s+([a-z_0-9]+)\s", l)

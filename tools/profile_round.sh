@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"  # (the batch sweep would mix other launch shapes into the per-kernel averages)
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/stats.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -34,12 +34,22 @@ try:
     rev = open("$R/.git_rev").read().strip()   # written by tools/gpu.sh: the pushed snapshot has no .git
 except Exception:
     rev = "not recorded"
+def src_sha(files):  # bench.py::kernel_source_fingerprint: which kernel sources these counters belong to
+    import hashlib
+    h = hashlib.sha1()
+    for name in files:
+        try:
+            h.update(open("$R/riffusion-hobby_amd/csrc/" + name, "rb").read())
+        except OSError:
+            h.update(b"?")
+    return h.hexdigest()[:12]
+SRC = {"gl_iter_pmc.json": ("rfx_gl.hip", "rfx_core.h", "rfx_frame.hip.h"), "forward_pmc.json": ("rfx_stft.hip", "rfx_core.h", "rfx_frame.hip.h")}
 for key, fname in (("gl_iter_kernel<2>", "gl_iter_pmc.json"), ("stft_mel2_kernel", "forward_pmc.json")):
     res = {}
     for k in tables["FETCH_SIZE"]:
         if key not in k: continue
         f_kb = tables["FETCH_SIZE"][k][1]; w_kb = tables["WRITE_SIZE"].get(k, (0, 0.0))[1]
-        res = {"kernel": k, "git": rev, "batch_tiles": 64, "frames_per_tile": 512, "launches_sampled": tables["FETCH_SIZE"][k][0], "FETCH_SIZE_kb_raw": f_kb, "WRITE_SIZE_kb_raw": w_kb,
+        res = {"kernel": k, "git": rev, "src_sha": src_sha(SRC[fname]), "src_files": list(SRC[fname]), "batch_tiles": 64, "frames_per_tile": 512, "launches_sampled": tables["FETCH_SIZE"][k][0], "FETCH_SIZE_kb_raw": f_kb, "WRITE_SIZE_kb_raw": w_kb,
                "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0,
                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE uncorrected; "
                        "each counter group collected in its own rocprofv3 --kernel-trace --pmc run of bench.py"}
