@@ -197,9 +197,19 @@ class ClockSampler:
         self.samples, self.path, self.kind = [], None, None
         self._stop = threading.Event()
         self._thread = None
+        # the node's other GPUs show up in sysfs too (busy with other people's work): take the card whose PCI address is this device's
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(index or 0)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
         cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if cards:
-            self.path, self.kind = cards[min(index or 0, len(cards) - 1)], "pp_dpm_sclk"
+        mine = [c for c in cards if want and os.path.basename(os.path.realpath(os.path.dirname(c))) == want]
+        if mine:
+            self.path, self.kind = mine[0], f"pp_dpm_sclk of {want}"
+        elif len(cards) == 1:
+            self.path, self.kind = cards[0], "pp_dpm_sclk (the only card)"
 
     def _read(self):
         try:
