@@ -43,9 +43,10 @@ typedef enum {
  * already resolved to samples (spectrogram_params.py:62-81). */
 typedef struct {
   int32_t sample_rate;
-  int32_t n_fft;        /* 17640 at 44.1 kHz: that geometry (with win 4410, hop 441) runs on the specialised engine; n_fft = 40 h, */
-  int32_t win_length;   /* 4410     win = 10 h with h in {80 .. 480} (48 kHz: 19200 / 4800 / 480, 32, 24, 16, 8 kHz) on the row-family   */
-  int32_t hop_length;   /* 441      kernels, every other one (22.05 kHz: 8820 / 2205 / 220, ...) on the generic engine (4.5) */
+  int32_t n_fft;        /* 17640 at 44.1 kHz: that geometry (win 4410, hop 441) runs on the specialised engine;        */
+  int32_t win_length;   /* 4410     n_fft = 40 h, win = 10 h with h in {80 .. 480} (48 kHz: 19200 / 4800 / 480; 32, 24, 16, 8 kHz) and     */
+  int32_t hop_length;   /* 441      n_fft = 20 h', win = 5 h' (22.05 kHz: 8820 / 2205 / 220) on the row-family kernels;    */
+                        /*          every other geometry (11.025 kHz, 96 kHz, custom durations) on the generic engine      */
   int32_t n_mels;       /* num_frequencies */
   int32_t max_mel_iters;
 } rfx_params;

@@ -561,8 +561,13 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
             const double den = n * sxx - sx * sx;
             const double slope = n > 1 ? (n * sxy - sx * sy) / den : 0.0, icpt = (sy - slope * sx) / n;
             const float af = (float)icpt, sf = (float)slope;
+            // tolerance RELATIVE to the group's largest weight (an area-normalised bank has weights ~1e-2: an absolute 1e-6 would
+            // admit 1e-4 relative there).  Measured on the reference's banks (tools/probe_line_fit.py): 0.72e-7 of the group
+            // maximum for htk / no norm, 1.16e-7 for slaney - one ulp of the largest weight; 4e-7 leaves a factor of three.
+            double wmax = 0;
+            for (int i = 0; i < n; ++i) wmax = fmax(wmax, fabs((double)w[f0 + i]));
             for (int i = 0; i < n; ++i)
-              if (fabs((double)af + (double)sf * i - (double)w[f0 + i]) > 1e-6) wave_ok = false;
+              if (fabs((double)af + (double)sf * i - (double)w[f0 + i]) > 4e-7 * wmax) wave_ok = false;
             lin[(size_t)(2 * which) * M + g2] = af;
             lin[(size_t)(2 * which + 1) * M + g2] = sf;
           }

@@ -502,15 +502,25 @@ class Plan:
 # Plans are cached, least recently used first out: a plan pins its tables on the device (the dense filterbank alone is
 # 18 MB at the default parameters), and a server that builds its parameters from image EXIF (cli.py:77-87) would otherwise
 # grow the cache with every distinct parameter set for ever.  An evicted plan is destroyed when its last user lets go of it.
+# The bound is PER DEVICE (round 5): one process driving eight GPUs with two parameter sets holds sixteen plans, and a miss on
+# one GPU never evicts another GPU's plan (a rebuild is a filterbank construction, hipMallocs and an 18 MB upload; an eviction's
+# hipFree synchronises its device).
 PLAN_CACHE_SIZE = max(1, int(os.environ.get("RFX_PLAN_CACHE", "8")))
 _plans: "collections.OrderedDict[T.Tuple[T.Any, int, str, str, str, str], Plan]" = collections.OrderedDict()
 _plans_lock = threading.Lock()
 
 
+def _evict_over_bound(plans: "collections.OrderedDict", dev_index: int, bound: int) -> None:
+    """Drop the least recently used plans OF ONE DEVICE until at most `bound` of them are cached (key[1] is the device index)."""
+    mine = [k for k in plans if k[1] == dev_index]  # OrderedDict iterates least recently used first
+    for k in mine[: max(0, len(mine) - bound)]:
+        del plans[k]  # dropped from the cache; freed when the last converter holding it goes
+
+
 def get_plan(params: T.Any, device: T.Union[str, torch.device], gl_form: str = "auto", frame_engine: str = "auto",
              plan_layout: str = "auto", imel_form: str = "auto") -> Plan:
-    """Plans are immutable and cached per (frozen params, device, options), at most PLAN_CACHE_SIZE of them (least recently
-    used evicted): constructing a converter per request, as the reference's server does (server.py:159), costs a
+    """Plans are immutable and cached per (frozen params, device, options), at most PLAN_CACHE_SIZE of them per device (least
+    recently used evicted): constructing a converter per request, as the reference's server does (server.py:159), costs a
     dictionary lookup.
 
     `gl_form` picks the Griffin-Lim device form (rfx_plan_options.gl_form): "auto" (per call, from the batch
@@ -527,8 +537,7 @@ def get_plan(params: T.Any, device: T.Union[str, torch.device], gl_form: str = "
         if plan is None:
             plan = Plan(params, dev, gl_form, frame_engine, plan_layout, imel_form)
             _plans[key] = plan
-            while len(_plans) > PLAN_CACHE_SIZE:
-                _plans.popitem(last=False)  # dropped from the cache; freed when the last converter holding it goes
+            _evict_over_bound(_plans, dev.index, PLAN_CACHE_SIZE)
         else:
             _plans.move_to_end(key)
     return plan

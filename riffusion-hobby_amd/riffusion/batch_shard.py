@@ -20,6 +20,7 @@ spectrogram_image_converter.py:65-91); a rank's shard is produced chunk by chunk
 chunk is copied to a pinned host buffer on a side stream while the next chunk computes: both copies are off the critical path.
 """
 import typing as T
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -27,9 +28,24 @@ import torch.distributed as dist
 GATHER_MODES = ("all", "rank0", "none")
 
 
+_warned_default_gather = False
+
+
 def default_gather(group: T.Any) -> str:
-    """`gather=None` at the entry points: with a process group the mode that scales ("none": every rank returns its own
-    clips, no data-path collective); without one the question does not arise."""
+    """`gather=None` at the entry points.  Without a process group the question does not arise.  With one, the default is the
+    mode that scales ("none": every rank returns its OWN clips, no data-path collective) - which is NOT what rounds 2-3 of this
+    library did ("all": every rank got the whole batch), so the first such call of a process says so once: a caller that relied
+    on the old default gets a different leading dimension, and should pass `gather="all"` (or "rank0") explicitly."""
+    global _warned_default_gather
+    if group is not None and not _warned_default_gather:
+        pg = _resolve_group(group)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(pg) > 1:
+            _warned_default_gather = True
+            warnings.warn(
+                "a process group was passed without `gather=`: every rank returns only its own shard of the batch "
+                "(gather=\"none\"); pass gather=\"all\" or \"rank0\" for the whole batch (the default of earlier versions was \"all\")",
+                stacklevel=3,
+            )
     return "none"
 
 
@@ -183,13 +199,16 @@ class ChunkSink:
 class ChunkSource:
     """
     Input side of a shard that is consumed chunk by chunk: `get(i)` returns chunk i = rows [bounds[i][0], bounds[i][1]) of
-    `items` as a tensor on `device`.
+    `items` as a tensor on `device`; `prefetch(i + 1)`, called AFTER chunk i's kernels have been queued, stages and uploads
+    the next chunk underneath them.
 
     Device input: a view (nothing to move).  Host input, one chunk (one tile per request): one plain upload on the compute
-    stream.  Host input, several chunks: chunk i+1 is copied into one of two pinned staging blocks and uploaded on a SIDE
-    stream while chunk i computes - `get(i)` queues that before it returns chunk i, so by the time the caller has launched
-    chunk i's kernels the next upload is already in flight; the compute stream waits for a chunk's upload event, never the
-    host.  Only chunk 0's upload is exposed (it has nothing to hide behind).
+    stream.  Host input, several chunks: a chunk is copied into one of two pinned staging blocks (a host memcpy, ~50 MB for
+    64 tiles) and uploaded on a SIDE stream; the compute stream waits for a chunk's upload event, never the host.  Until
+    round 5 `get(i)` did the staging copy of chunk i+1 BEFORE it returned chunk i, so the GPU idled during that memcpy
+    whenever the host was not running ahead (for chunk 0 always); now the caller launches chunk i first and prefetches then.
+    A caller that never calls `prefetch` still works: `get(i)` uploads chunk i on demand.  Chunk 0's upload is always exposed
+    (it has nothing to hide behind).
     """
 
     def __init__(self, items: torch.Tensor, bounds: T.Sequence[T.Tuple[int, int]], device: torch.device):
@@ -212,7 +231,7 @@ class ChunkSource:
             if self.pin_free[j] is not None:
                 self.pin_free[j].synchronize()  # the upload that last read this block (two chunks ago) has long finished
             src = self.pinned[j][: b - a]
-            src.copy_(self.items[a:b])  # pageable -> pinned on the host, while the GPU computes the previous chunk
+            src.copy_(self.items[a:b])  # pageable -> pinned on the host, while the GPU computes the chunk queued before
         with torch.cuda.stream(self.side):
             dev = src.to(self.device, non_blocking=True)
             done = torch.cuda.Event()
@@ -221,13 +240,19 @@ class ChunkSource:
             self.pin_free[i & 1] = done
         self.ready[i] = (dev, done)
 
+    def prefetch(self, i: int) -> None:
+        """Stage and upload chunk i now (no-op for device input, a single chunk, an index past the end or a chunk already in
+        flight).  Call it once the kernels of the chunk before have been launched."""
+        if self.staged and 0 <= i < len(self.bounds) and i not in self.ready:
+            self._upload(i)
+
     def get(self, i: int) -> torch.Tensor:
         a, b = self.bounds[i]
         if not self.staged:
             return self.items[a:b].to(self.device)
+        if i not in self.ready:
+            self._upload(i)  # nobody prefetched it: upload on demand
         dev, done = self.ready.pop(i)
-        if i + 1 < len(self.bounds):
-            self._upload(i + 1)
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(done)
         dev.record_stream(cur)  # allocated on the side stream, consumed on the compute stream

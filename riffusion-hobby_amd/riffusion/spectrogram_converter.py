@@ -133,9 +133,9 @@ class SpectrogramConverter:
     def audio_from_spectrogram(self, spectrogram: np.ndarray, apply_filters: bool = True) -> T.Any:
         """(channels, n_mels, T) mel amplitudes -> audio segment with that many channels."""
         amplitudes_mel = torch.from_numpy(np.ascontiguousarray(spectrogram)).to(self.device)
-        waveform = self.waveform_from_mel_amplitudes(amplitudes_mel)
-        # peak-normalise + int16 truncation on the device (audio_util.py:22-28), one D2H of int16
         plan = self._plan()
+        waveform = self._waveform_from_mel(plan, amplitudes_mel)
+        # peak-normalise + int16 truncation on the device (audio_util.py:22-28), one D2H of int16
         pcm, _ = plan.pcm16(waveform, channels=waveform.shape[0], normalize=True)
         segment = audio_util.segment_from_pcm16(pcm[0].cpu().numpy(), self.p.sample_rate)
         if apply_filters:
@@ -163,7 +163,14 @@ class SpectrogramConverter:
         `angles0` (B, n_stft, T) inject the two random initialisations (tests); otherwise they are drawn
         on the device from `seed` / torch's global generator.
         """
-        plan = self._plan()
+        return self._waveform_from_mel(self._plan(), amplitudes_mel, spec0=spec0, angles0=angles0, seed=seed,
+                                       channels_per_clip=channels_per_clip)
+
+    def _waveform_from_mel(self, plan: T.Any, amplitudes_mel: torch.Tensor, *, spec0: T.Optional[torch.Tensor] = None,
+                           angles0: T.Optional[torch.Tensor] = None, seed: T.Optional[int] = None,
+                           channels_per_clip: T.Optional[int] = None) -> torch.Tensor:
+        """`waveform_from_mel_amplitudes` on a plan the caller already holds (the batch entry points fetch it once per call,
+        not once per chunk and stage: a fetch is a lock and a dictionary lookup, and after an eviction a rebuild)."""
         mel = amplitudes_mel.to(self.device)
         B, _, Tn = mel.shape
         cpc = B if channels_per_clip is None else channels_per_clip

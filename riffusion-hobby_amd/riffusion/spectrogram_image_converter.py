@@ -116,7 +116,8 @@ class SpectrogramImageConverter:
         that range check runs: None (default) at once for a host tensor, and for a device tensor as a flag
         computed on the device and read where the call synchronises anyway (the copy of the result to the
         host) - no host sync on the one-tile-per-request path; True: at once, with a host sync; False: never
-        (`return_device=True` with a device input never synchronises, so None checks nothing there).
+        (`return_device=True` with a device input never synchronises and so cannot raise: there None turns a failed check
+        into an all-zero result - silence, not garbage audio - and attaches the device flag as `result.range_ok`).
         Host tiles are uploaded chunk by chunk through pinned memory on a side stream (`batch_shard.ChunkSource`).
 
         `group`: a `torch.distributed` process group (or True for the default group).  Every rank
@@ -175,16 +176,25 @@ class SpectrogramImageConverter:
             source = batch_shard.ChunkSource(imgs, bounds, plan.device)
             for i, (a, b) in enumerate(bounds):
                 mel = plan.image_decode(source.get(i), self.p.stereo, lut)
-                wave = conv.waveform_from_mel_amplitudes(mel, seed=base_seed + 2 * a, channels_per_clip=C)
+                wave = conv._waveform_from_mel(plan, mel, seed=base_seed + 2 * a, channels_per_clip=C)
                 if return_waveform:
-                    sink.put(a - lo, b - lo, wave.reshape(b - a, C, -1))
+                    out = wave.reshape(b - a, C, -1)
                 else:
                     dst = sink.rows(a - lo, b - lo)  # device sink: the PCM kernel writes the batch rows in place
-                    sink.put(a - lo, b - lo, plan.pcm16(wave, channels=C, normalize=True, out=dst)[0])
+                    out = plan.pcm16(wave, channels=C, normalize=True, out=dst)[0]
+                # this chunk's kernels are queued: the host stages and uploads the next chunk underneath them
+                source.prefetch(i + 1)
+                sink.put(a - lo, b - lo, out)
             return sink.finish()  # a rank with an empty shard still joins the collective with 0 rows
 
         result = batch_shard.sharded_map(convert, n_total, group, gather)
         if return_device:
+            if range_ok is not None:
+                # nothing on this path ever synchronises, so the deferred check cannot raise here: out-of-range (or NaN) input
+                # yields SILENCE instead of garbage audio (one fused multiply on the device, no host sync), and the flag travels
+                # with the result for a caller that wants to look: `result.range_ok` (0-dim bool tensor on the device)
+                result = result * range_ok.to(result.dtype)
+                result.range_ok = range_ok
             return result
         if result.is_cuda:
             host = torch.empty(result.shape, dtype=result.dtype, pin_memory=True)  # gathered batch: one pinned copy

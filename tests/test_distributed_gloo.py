@@ -76,6 +76,15 @@ def _map_worker(rank, world, port, n_items):
     assert result_rows(n_items, dist.group.WORLD, "all") == (0, n_items) and result_rows(n_items) == (0, n_items)
     with pytest.raises(ValueError):
         sharded_map(convert, n_items, dist.group.WORLD, gather="everyone")
+    # round 5: `gather=None` at an entry point with a multi-rank group warns ONCE per process that the default is the own shard
+    import warnings
+
+    from riffusion import batch_shard
+
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        assert batch_shard.default_gather(dist.group.WORLD) == "none" and batch_shard.default_gather(True) == "none"
+    assert len(seen) == 1 and "own shard" in str(seen[0].message) and issubclass(seen[0].category, UserWarning)
     # a sub-group whose rank 0 is global rank 1: "rank0" means the GROUP's first rank
     sub = dist.new_group([1, 0]) if world == 2 else None
     if sub is not None:

@@ -244,6 +244,11 @@ def test_float_range_check_modes():
             conv.audio_from_spectrogram_images(x.cuda(), seed=1, validate=True, return_device=True)
         out = conv.audio_from_spectrogram_images(x.cuda(), seed=1, validate=False)         # the server path: no check
         assert out.shape == ref.shape
+        # round 5: return_device + device input never synchronises, so it cannot raise - a failed check gives silence and a flag
+        dev = conv.audio_from_spectrogram_images(x.cuda(), seed=1, return_device=True)
+        assert dev.is_cuda and dev.shape == ref.shape and not bool(dev.range_ok) and int(dev.abs().max()) == 0
+    dev = conv.audio_from_spectrogram_images(good.cuda(), seed=1, return_device=True)
+    assert bool(dev.range_ok) and np.array_equal(dev.cpu().numpy(), ref)
 
 
 def test_plan_cache_returns_device_memory():
