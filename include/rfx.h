@@ -121,6 +121,14 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
 int rfx_plan_griffinlim_engine(const rfx_plan* plan);
 /* the form (RFX_GL_FORM_RUNS / _FRAMES) an rfx_griffinlim call of B x T frames takes on this plan */
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T);
+/* How one launch of the run-based form cuts the call's B*T frames (counted clip after clip) into runs, one per workgroup: returns
+ * the number of runs and, if run_starts != NULL, writes min(runs + 1, capacity) run boundaries (run b = frames
+ * [run_starts[b], run_starts[b + 1])).  which = 0: the first (synthesis-only) launch, 1: the iterations.  0 for a generic plan.
+ * No device work: the partition is a function of (chip, B, T) alone - results are bit-reproducible call to call.  (tests) */
+int rfx_griffinlim_runs(const rfx_plan* plan, int B, int T, int which, int64_t* run_starts, int capacity);
+/* the arithmetic behind it, callable without a plan or a GPU (tests): first frame of run b of `runs` over n_frames frames when
+ * the first h runs weigh w1 and the others w2 (per mille of the mean run length) */
+int64_t rfx_debug_run_start(int64_t b, int64_t runs, int64_t n_frames, int64_t h, int64_t w1, int64_t w2);
 /* frames torch.stft(center=True, pad_mode="reflect") makes of Lw samples: 1 + (Lw + 2*(n_fft/2) - n_fft) / hop, i.e.
  * 1 + Lw/hop for even n_fft and 1 + (Lw-1)/hop for odd n_fft; 0 when Lw <= n_fft/2 (the reference raises there).
  * Every forward entry point below produces exactly this many frames. */

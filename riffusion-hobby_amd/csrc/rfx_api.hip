@@ -84,12 +84,22 @@ struct EventList {
 };
 }  // namespace
 
+#ifndef RFX_GL_RUN_SKEW
+#define RFX_GL_RUN_SKEW 0
+#endif
+#ifndef RFX_GL_RUN_SKEW0
+#define RFX_GL_RUN_SKEW0 0
+#endif
+
 struct rfx_plan {
   rfx_params p;
   int device;
   int num_cus;
   int n_stft;
   int gl_wgs_per_cu = 1;    // resident Griffin-Lim workgroups per CU on this device (occupancy query at creation)
+  // how much longer the run of a first-dispatched workgroup is than the mean (per mille; its CU partner's is that much shorter):
+  // rfx_kernels.h GlArgs::run_w1.  [0]: the synthesis-only launch (MODE 0), [1]: the iterations.  Measured optimum on MI355X.
+  int gl_run_skew[2] = {RFX_GL_RUN_SKEW0, RFX_GL_RUN_SKEW};
   int imel_variant = 0;     // debugging override read once at creation: 0 = best, 1 = uniform groups, 2 = general
   unsigned long long* timing = nullptr;  // RFX_TIMING builds only
   cf* d_tw1 = nullptr;      // [21][441]
@@ -317,6 +327,8 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   }
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
   if (const char* e = abl_env("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char* e = abl_env("RFX_GL_SKEW")) pl->gl_run_skew[1] = atoi(e);
+  if (const char* e = abl_env("RFX_GL_SKEW0")) pl->gl_run_skew[0] = atoi(e);
   pl->imel_variant = abl_env("RFX_IMEL_GENERAL") ? 2 : abl_env("RFX_IMEL_UNIFORM") ? 1 : abl_env("RFX_IMEL_NO_PAIR") ? 3 : 0;  // 3: best one-frame kernel
   // which Griffin-Lim device form a call takes: the options of rfx_plan_create_ex decide; the environment (read here, once)
   // only changes what RFX_GL_FORM_AUTO / the default threshold mean, for experiments
@@ -324,7 +336,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   if (const char* e = abl_env("RFX_GL_LATENCY_FRAMES")) pl->gl_latency_frames_per_slot = atoi(e) > 0 ? atoi(e) : 4;
   pl->gl_form = opt.gl_form;
   if (opt.gl_frames_per_slot > 0) pl->gl_latency_frames_per_slot = opt.gl_frames_per_slot;
-#ifdef RFX_TIMING
+#if defined(RFX_TIMING) || defined(RFX_WGCLOCK)
   if (const char* e = getenv("RFX_TIMING_PTR")) pl->timing = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
 
@@ -846,6 +858,38 @@ static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
   return plan->gl_latency_mode && (long long)B * T <= (long long)plan->gl_latency_frames_per_slot * plan->num_cus * plan->gl_wgs_per_cu;
 }
 
+// The runs of one launch of the run-based Griffin-Lim kernel: the batch's B*T frames, counted clip after clip, are cut into one run
+// per resident workgroup slot of the chip and never more (a launch of 520 workgroups on 512 slots runs eight of them alone in a
+// second wave: the ceil(slots / B) runs per clip of rounds 1-4 did that for every B that does not divide the slot count); every run
+// at least 10 frames long, so that a hop block is shared by at most two runs.  Round 5, second step: the runs of the workgroups the
+// dispatcher places first (one per CU, blocks 0 .. num_cus-1) are `skew` per mille LONGER than the mean and those of the workgroups
+// that join them that much shorter (rfx_kernels.h, GlArgs::run_h) - only when every CU gets exactly its two workgroups (the case
+// that was measured) and the short runs keep 11 frames; otherwise all runs are equal (+- 1 frame).  which = 0: the synthesis-only
+// first launch, 1: the iterations.
+struct GlPartition { int runs, h, w1, w2; };
+static GlPartition gl_partition(const rfx_plan* plan, int B, int T, int which) {
+  const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu, N = (long long)B * T;
+  long long nruns = N / 10;
+  if (nruns > slots) nruns = slots;
+  if (nruns < 1) nruns = 1;
+  int skew = plan->gl_run_skew[which ? 1 : 0];
+  const bool full = plan->gl_wgs_per_cu == 2 && nruns == slots;
+  if (!full || skew < 0 || skew > 400 || (N * (1000 - skew)) / (1000LL * nruns) < 11) skew = 0;
+  return GlPartition{(int)nruns, plan->num_cus, 1000 + skew, 1000 - skew};
+}
+
+int rfx_griffinlim_runs(const rfx_plan* plan, int B, int T, int which, int64_t* run_starts, int capacity) {
+  if (!plan || B <= 0 || T < 2 || plan->generic) return 0;
+  const GlPartition p = gl_partition(plan, B, T, which);
+  if (run_starts)
+    for (int b = 0; b <= p.runs && b < capacity; ++b) run_starts[b] = rfx::gl_run_start(b, p.runs, (long long)B * T, p.h, p.w1, p.w2);
+  return p.runs;
+}
+
+int64_t rfx_debug_run_start(int64_t b, int64_t runs, int64_t n_frames, int64_t h, int64_t w1, int64_t w2) {
+  return rfx::gl_run_start(b, runs, n_frames, h, w1, w2);
+}
+
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T) {
   if (!plan || B <= 0 || T < 2) return RFX_GL_FORM_AUTO;
   if (plan->generic) return RFX_GL_FORM_FRAMES;  // the generic engine has one form: frame kernels + fold
@@ -1080,15 +1124,16 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   g.mom = momentum / (1.f + momentum);
   g.seed = seed;
   g.timing = plan->timing;
-  // runs: the batch's B*T frames, counted clip after clip, are cut into equal runs (+- 1 frame), one per resident workgroup slot
-  // of the chip and never more (a launch of 520 workgroups on 512 slots runs eight of them alone in a second wave: the
-  // ceil(slots / B) runs per clip of rounds 1-4 did that for every B that does not divide the slot count); every run at least
-  // 10 frames long, so that a hop block is shared by at most two runs.  At B = 64, T = 512 this is the old partition exactly.
-  const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu;
-  long long nruns = ((long long)B * T) / 10;
-  if (nruns > slots) nruns = slots;
-  if (nruns < 1) nruns = 1;
-  const int nblocks = (int)nruns;
+  // runs: the batch's B*T frames, counted clip after clip, are cut into one run per resident workgroup slot (gl_partition)
+  GlPartition part = gl_partition(plan, B, T, 0);
+  const int nblocks = part.runs;
+  auto set_partition = [&](int which) {
+    part = gl_partition(plan, B, T, which);
+    g.run_h = part.h;
+    g.run_w1 = part.w1;
+    g.run_w2 = part.w2;
+  };
+  set_partition(0);
 
   // optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg)
   EventList events;
@@ -1106,11 +1151,18 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
     }
   };
   set_io(1, 2, 0);  // MODE 0 reads nothing; writes x_0
+#ifdef RFX_WGCLOCK
+  g.launch = 0;
+#endif
   RFX_HIP(launch_gl_iter(0, g, nblocks, stream));
   if (h_launch_ms) RFX_HIP(hipEventRecord(ev[1], stream));
+  set_partition(1);
   for (int it = 1; it <= n_iter; ++it) {
     // iteration `it` analyses x_{it-1} - m*x_{it-2} and writes x_it
     set_io((it - 1) % 3, (it + 1) % 3 /* == (it-2) mod 3 */, it % 3);
+#ifdef RFX_WGCLOCK
+    g.launch = it;
+#endif
     RFX_HIP(launch_gl_iter(it == 1 ? 1 : 2, g, nblocks, stream));
     if (h_launch_ms) RFX_HIP(hipEventRecord(ev[it + 1], stream));
   }

@@ -68,15 +68,22 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ThreadId t = thread_id();
   const FrameCtx f = frame_ctx(smem, t, g.tw1, g.tw2);
+#ifdef RFX_WGCLOCK
+  // diagnostic build (tools/probe_wgclock.py): when does every workgroup of every launch start and end, and on which XCD / CU -
+  // is the tail a launch boundary exposes the same workgroups every time (placement) or a different set each launch (chance)?
+  const unsigned long long wg_t0 = wall_clock64(), wg_c0 = __builtin_readcyclecounter();  // 100 MHz wall clock, shader-clock counter
+#endif
 
   // Run r of the launch's gridDim.x runs owns the frames [r N / R, (r + 1) N / R) of the batch's N = B T frames, counted clip
   // after clip: every resident workgroup slot gets the same number of frames (+- 1) WHATEVER the batch size is (the host keeps
   // R <= slots and every run at least 10 frames long).  A run that crosses a clip boundary is walked as one SEGMENT per clip;
   // the segments of a clip belong to consecutive runs, so the two runs that share a hop block always differ in parity.
   // (Until round 5 every clip was cut into ceil(slots / B) runs of its own: B = 65 launched 520 workgroups for 512 slots.)
+  // Round 5, second step: the runs are NOT equal any more - the workgroups dispatched first (one per CU) get longer runs than
+  // the ones that join them, by the ratio of the rates the pair was measured to run at (GlArgs::run_h / run_w1 / run_w2).
   const long long nfr_all = (long long)g.B * g.T;  // < 2^31 (checked by the host)
-  const int gf_end = (int)(((long long)(blockIdx.x + 1) * nfr_all) / gridDim.x);
-  int gf = (int)(((long long)blockIdx.x * nfr_all) / gridDim.x);
+  const int gf_end = (int)gl_run_start((long long)blockIdx.x + 1, gridDim.x, nfr_all, g.run_h, g.run_w1, g.run_w2);
+  int gf = (int)gl_run_start(blockIdx.x, gridDim.x, nfr_all, g.run_h, g.run_w1, g.run_w2);
   const int par = blockIdx.x & 1;
   const int nblk = g.T - 1;  // hop blocks kept by istft's centre trim
 
@@ -297,6 +304,17 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #pragma unroll
   for (int j = 0; j < 9; ++j) emit(t1 - 4 + j, acc[j]);
   }  // next segment of the run (another clip)
+#ifdef RFX_WGCLOCK
+  __syncthreads();
+  if (g.timing && threadIdx.x == 0) {
+    unsigned long long* rec = g.timing + ((size_t)g.launch * gridDim.x + blockIdx.x) * 4;
+    rec[0] = wg_t0;
+    rec[1] = wall_clock64();
+    rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    rec[3] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20)   // HW_REG_XCC_ID in the low four bits,
+             | ((__builtin_readcyclecounter() - wg_c0) << 8);                 // shader cycles the workgroup lived above them
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------

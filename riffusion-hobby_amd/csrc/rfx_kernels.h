@@ -20,10 +20,28 @@ struct GlArgs {
   const cf* tw2;              // [21][21]
   const float* win;           // [4410]
   int B, T, L, Lpad;          // (the runs of a launch are its workgroups: gridDim.x)
+  // Run lengths by dispatch order (round 5; gl_run_start below): the first `run_h` workgroups of a launch are the ones the
+  // dispatcher places first - one per CU - and every later one joins a CU that already runs one.  The earlier workgroup's waves
+  // are the older ones and win the CU's issue arbitration: measured (tools/probe_wgclock.py, 64 tiles) it finishes its 64 frames
+  // in 656 us, its partner in 738 us, every launch, on every CU (spread 0.3 % / 0.1 %) - and for the last tenth of the launch
+  // every CU runs one workgroup alone, at three quarters of its two-workgroup rate.  So the early workgroups get run_w1 / 1000
+  // and the late ones run_w2 / 1000 of the mean run length, and the pair finishes together.
+  int run_h, run_w1, run_w2;
   float mom;                  // momentum / (1 + momentum)
   unsigned long long seed;
   unsigned long long* timing;  // optional [nblocks][8] phase timers (RFX_TIMING builds only)
+#ifdef RFX_WGCLOCK
+  int launch;                  // diagnostic build: index of this launch inside one rfx_griffinlim call (tools/probe_wgclock.py)
+#endif
 };
+
+// first frame of run b when the launch's N frames are cut into `runs` runs: the runs b < h weigh w1, the others w2 (integers,
+// per mille of the mean).  Exact integer arithmetic, the same on the host (checks) and in the kernel; N < 2^31, weights < 2^11.
+RFX_HD long long gl_run_start(long long b, long long runs, long long N, long long h, long long w1, long long w2) {
+  const long long hb = b < h ? b : h, ht = runs < h ? runs : h;
+  const long long Wb = w1 * hb + w2 * (b - hb), Wt = w1 * ht + w2 * (runs - ht);
+  return N * Wb / Wt;
+}
 
 hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t stream);
 // per-device set-up, called by rfx_plan_create with the plan's device current

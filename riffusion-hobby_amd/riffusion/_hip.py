@@ -76,6 +76,8 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_plan_create": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     "rfx_plan_create_ex": (c_int, [ctypes.POINTER(RfxParams), c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "rfx_griffinlim_form": (c_int, [c_void_p, c_int, c_int]),
+    "rfx_griffinlim_runs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int]),
+    "rfx_debug_run_start": (ctypes.c_int64, [ctypes.c_int64] * 6),
     "rfx_stft_frames": (c_int, [c_void_p, c_int]),
     "rfx_plan_imel_kernel": (c_int, [c_void_p]),
     "rfx_plan_imel_unit_form": (c_int, [c_void_p]),

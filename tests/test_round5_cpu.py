@@ -125,3 +125,37 @@ def test_default_gather_without_a_process_group_is_silent():
         warnings.simplefilter("error")
         assert batch_shard.default_gather(None) == "none"
         assert batch_shard.default_gather(True) == "none"  # no process group initialised: nothing to warn about
+
+
+def _lib():
+    import ctypes
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "riffusion-hobby_amd", "librfx.so"))
+    lib.rfx_debug_run_start.restype = ctypes.c_int64
+    lib.rfx_debug_run_start.argtypes = [ctypes.c_int64] * 6
+    return lib
+
+
+@pytest.mark.parametrize("B,T", [(64, 512), (65, 512), (100, 512), (48, 512), (128, 512), (11, 512), (512, 40), (10, 1024), (3, 2000)])
+@pytest.mark.parametrize("skew", [0, 60, 100, 250])
+def test_run_partition_by_dispatch_order_is_a_partition(B, T, skew):
+    """rfx_kernels.h::gl_run_start (through the C ABI, no GPU): the runs of a launch tile the frames exactly, in order, the first
+    h of them longer by 2 * skew per mille of the mean than the others, none shorter than 11 frames when the host's admission rule
+    (rfx_api.hip::gl_partition) lets the skew through - so a hop block (10 frames) is shared by at most two runs."""
+    lib = _lib()
+    runs, h, N = 512, 256, B * T
+    admitted = N // 10 >= runs and (N * (1000 - skew)) // (1000 * runs) >= 11
+    w1, w2 = (1000 + skew, 1000 - skew) if admitted else (1000, 1000)
+    if N // 10 < runs:
+        runs = max(1, N // 10)
+    st = [lib.rfx_debug_run_start(b, runs, N, h, w1, w2) for b in range(runs + 1)]
+    assert st[0] == 0 and st[-1] == N and all(a < b for a, b in zip(st, st[1:]))
+    lens = np.diff(st)
+    assert lens.min() >= 10
+    if w1 == w2:
+        assert lens.max() - lens.min() <= 1 and st == [N * b // runs for b in range(runs + 1)]  # the equal partition, exactly
+    else:
+        first, second = lens[:h], lens[h:]
+        assert first.max() - first.min() <= 1 and second.max() - second.min() <= 1 and lens.min() >= 11
+        mean = N / runs
+        assert abs(first.mean() / mean - w1 / 1000) < 2e-3 and abs(second.mean() / mean - w2 / 1000) < 2e-3

@@ -27,9 +27,13 @@ def kernels_of(src: str, extra=()):
             mm = re.search(r"\.amdhsa_" + k + r"\s+(\S+)", body)
             return int(mm.group(1)) if mm and mm.group(1).isdigit() else None
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-        sp = re.search(r"; ScratchSize: (\d+)", asm[asm.index(m.group(1) + ":"):])
+        start = asm.index(m.group(1) + ":")
+        code = asm[start:asm.index("s_endpgm", start)].split("\n")
+        n_instr = sum(1 for l in code if re.match(r"\s+[sv]_|\s+ds_|\s+buffer_|\s+global_|\s+scratch_|\s+flat_", l))
+        n_scratch = sum(1 for l in code if re.match(r"\s+scratch_", l))
         res.append({"file": os.path.basename(src), "kernel": name, "vgpr": field("next_free_vgpr"), "agpr_offset": field("accum_offset"),
-                    "scratch_bytes": field("private_segment_fixed_size"), "static_lds_bytes": field("group_segment_fixed_size")})
+                    "scratch_bytes": field("private_segment_fixed_size"), "static_lds_bytes": field("group_segment_fixed_size"),
+                    "instructions_static": n_instr, "scratch_instructions_static": n_scratch})
     return res
 
 
@@ -39,7 +43,7 @@ def main(argv):
     with ThreadPoolExecutor(8) as ex:
         rows = [r for rs in ex.map(kernels_of, srcs) for r in rs]
     for r in rows:
-        print(f"{r['file']:16s} vgpr {r['vgpr']:>4} scratch {r['scratch_bytes']:>4} lds {r['static_lds_bytes']:>6}  {r['kernel'][:140]}")
+        print(f"{r['file']:16s} vgpr {r['vgpr']:>4} scratch {r['scratch_bytes']:>4} B ({r['scratch_instructions_static']:>3} of {r['instructions_static']:>5} instructions) lds {r['static_lds_bytes']:>6}  {r['kernel'][:130]}")
     if not argv:
         with open(os.path.join(ROOT, "profiles", "isa_resources_latest.json"), "w") as fh:
             json.dump(rows, fh, indent=1)
