@@ -4,10 +4,9 @@ Round 5, CPU side (no GPU needed).
 * the line the InverseMelScale wave kernel uses instead of a weight table (rfx_api.hip, wave-kernel admission;
   rfx_imel.hip::imel_wave_kernel) stays within one ulp of a group's LARGEST weight on the reference's banks - the plan's gate is
   relative to that maximum (4e-7), not an absolute 1e-6 that an area-normalised bank (weights ~1e-2) would pass at 1e-4 relative;
-* independent pins of the inverse half of the oracle: its STFT / ISTFT against torch.stft / torch.istft (what torchaudio's
-  functional.griffinlim itself calls) and against scipy.signal (other people's code), its Griffin-Lim loop against a loop written
-  on torch.stft / torch.istft directly;
-* host logic added in round 5: per-device plan cache bound, the one-time warning for `group` without `gather`, ChunkSource.prefetch.
+* host logic added in round 5: per-device plan cache bound, the one-time warning for `group` without `gather`, ChunkSource.prefetch;
+* the run partition of the Griffin-Lim launches (rfx_kernels.h::gl_run_start through the C ABI): a partition of the frames for
+  every batch shape, equal runs by default, and with a dispatch-order skew (ablation builds) never a run under 11 frames.
 """
 import os
 import warnings
