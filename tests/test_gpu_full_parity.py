@@ -4,7 +4,7 @@ InverseMelScale 200 steps, Griffin-Lim 32 / 64 iterations).  One tile through th
 CPU, so these stay in the `-m gpu` suite.  Everything goes through the C ABI (librfx.so); the oracle is the checker.
 
 Gates (SURVEY.md 8(d)): InverseMelScale rel-L2 <= 1e-3 on the active bins and bit-equal pass-through elsewhere;
-Griffin-Lim waveform SNR >= 60 dB at 32 iterations and >= 40 dB at 64 with the same injected initial values;
+Griffin-Lim waveform SNR >= 60 dB at 32 iterations and >= 65 dB at 64 (stereo tile; measured 79 - 80) with the same injected initial values;
 production RNG path: spectral convergence next to the oracle's (3 %: the figure moves 1-2 % between random draws).
 """
 import os
@@ -125,7 +125,7 @@ def test_stereo_tile_griffinlim64_full_size(O):
     got = plan.griffinlim(plan.pack_magnitudes(want_lin.cuda()), 2, T_FULL, 64, 0.99, angles0_slots=plan.pack_complex(angles0.cuda())).cpu()
     s64 = snr_db(want, got)
     print(f"stereo Griffin-Lim 64 T=512: {s64:.1f} dB")
-    assert s64 >= 40.0
+    assert s64 >= 65.0  # measured 79.3 - 80.5 dB (rounds 2 - 5); the gate was 40 until round 5
     # joint peak normalisation + int16 truncation of the pair (audio_util.py:22-28) on the device result
     pcm, _ = plan.pcm16(got.cuda(), channels=2, normalize=True)
     assert np.array_equal(pcm[0].cpu().numpy(), O.pcm16_from_waveform(got.numpy(), normalize=True))

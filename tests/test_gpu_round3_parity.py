@@ -93,8 +93,11 @@ def test_oracle_tile_from_inside_the_headline_batch(O):
     s_full = snr_db(want, wave_full[b : b + 1].cpu())
     print(f"tile {b} inside the B = 64 batch vs oracle: InverseMelScale rel-L2 {rel:.2e}; Griffin-Lim 32 {s_gl:.1f} dB on identical "
           f"magnitudes, {s_full:.1f} dB for device SGD -> device Griffin-Lim")
-    assert s_gl >= 60.0
-    assert s_full >= 40.0  # the 1e-7-level SGD differences grow through 32 chaotic iterations
+    # SURVEY 8(d)'s floor is 60 dB; measured 89.3 - 92.5 dB (identical magnitudes) and 86.5 - 97.2 dB (device SGD feeding the device
+    # Griffin-Lim: its 1e-7-level differences grow through 32 chaotic iterations) over rounds 3 - 5 and two run partitions.  The
+    # gates sit ~15 dB under the lowest figure seen, not at the floor (they were 60 / 40 until round 5)
+    assert s_gl >= 75.0
+    assert s_full >= 70.0
 
 
 @pytest.mark.parametrize("scale,norm,kernel", [("htk", "slaney", 4), ("slaney", None, None), ("slaney", "slaney", None)])
