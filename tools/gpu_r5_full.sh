@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5, second visit: the whole GPU suite with the tightened gates, the new bench line, counters re-collected on HEAD
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5b; mkdir -p $OUT; cd $R
+# round 5: the whole GPU suite, the bench line, kernel stats and counters on HEAD (OUT = gpurun_out/r5g)
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5g; mkdir -p $OUT; cd $R
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1 || { echo "smoke failed"; tail -5 $OUT/smoke.txt; exit 1; }
 tail -1 $OUT/smoke.txt
 { ls /sys/class/drm/; for f in /sys/class/drm/card*/device/pp_dpm_sclk; do echo $f; cat $f; done; rocm-smi --showclocks 2>&1 | head -30; } > $OUT/clock_probe.txt 2>&1
