@@ -210,6 +210,22 @@ class ClockSampler:
             self.path, self.kind = mine[0], f"pp_dpm_sclk of {want}"
         elif len(cards) == 1:
             self.path, self.kind = cards[0], "pp_dpm_sclk (the only card)"
+        # socket power of the same device (round 5: is the clock a POWER limit?): hwmon power1_average / power1_input in microwatts,
+        # power1_cap = the limit the driver enforces
+        self.power, self.power_path, self.power_cap_w = [], None, None
+        if self.path:
+            dev_dir = os.path.dirname(self.path)
+            for name in ("power1_average", "power1_input"):
+                hit = sorted(glob.glob(os.path.join(dev_dir, "hwmon", "hwmon*", name)))
+                if hit:
+                    self.power_path = hit[0]
+                    break
+            try:
+                cap = sorted(glob.glob(os.path.join(dev_dir, "hwmon", "hwmon*", "power1_cap")))
+                if cap:
+                    self.power_cap_w = int(open(cap[0]).read().strip()) / 1e6
+            except Exception:
+                pass
 
     def _read(self):
         try:
@@ -221,11 +237,22 @@ class ClockSampler:
             return None
         return None
 
+    def _read_power(self):
+        try:
+            with open(self.power_path) as f:
+                return int(f.read().strip()) / 1e6
+        except Exception:
+            return None
+
     def _run(self):
         while not self._stop.is_set():
             v = self._read()
             if v:
                 self.samples.append(v)
+            if self.power_path:
+                w = self._read_power()
+                if w:
+                    self.power.append(w)
             self._stop.wait(0.004)
 
     def start(self):
@@ -244,8 +271,14 @@ class ClockSampler:
         if not self.samples:
             return {"source": None, "note": "no current-sclk file readable on this host"}
         xs = sorted(self.samples)
-        return {"source": self.kind, "samples": len(xs), "mhz_min": xs[0], "mhz_median": xs[len(xs) // 2], "mhz_max": xs[-1],
-                "note": "current sclk level of the driver, polled by a host thread during the timed steps"}
+        out = {"source": self.kind, "samples": len(xs), "mhz_min": xs[0], "mhz_median": xs[len(xs) // 2], "mhz_max": xs[-1],
+               "note": "current sclk level of the driver, polled by a host thread during the timed steps"}
+        if self.power:
+            ws = sorted(self.power)
+            out["socket_power_w"] = {"min": round(ws[0], 1), "median": round(ws[len(ws) // 2], 1), "max": round(ws[-1], 1), "cap": self.power_cap_w,
+                                     "source": os.path.basename(self.power_path),
+                                     "note": "the driver's averaged socket power during the timed steps (it lags: a 0.6 s timed region shows the ramp)"}
+        return out
 
 
 def kernel_source_fingerprint(files=("rfx_gl.hip", "rfx_core.h", "rfx_frame.hip.h")) -> str:
