@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: the diagnostic probes behind DESIGN 4.1's "power-bound" and "dispatch order" paragraphs, in one visit
-#   (here)   bash tools/build_variant.sh wgclock -DRFX_WGCLOCK -DRFX_ABLATION;  bash tools/build_variant.sh abl -DRFX_ABLATION
+#   (here)   bash tools/build_variants.sh wgclock:"-DRFX_WGCLOCK" abl:""
 #   (GPU)    bash tools/gpu.sh --timeout 900 -- 'bash tools/gpu_r5_probes.sh'
 # Results land in gpurun_out/r5p/; what is to be judged is copied into profiles/ (r05_power_clock_probe.txt, r05_wgclock_dispatch_order.txt).
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5p; mkdir -p $OUT; cd $R

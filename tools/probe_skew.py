@@ -1,6 +1,6 @@
 """
 Sweep of the Griffin-Lim run-length skew (rfx_api.hip::gl_partition; -DRFX_ABLATION build: RFX_GL_SKEW / RFX_GL_SKEW0 are read at
-plan creation):   bash tools/build_variant.sh abl -DRFX_ABLATION;  RFX_LIB_PATH=build_var/librfx_abl.so python tools/probe_skew.py
+plan creation):   bash tools/build_variants.sh abl:"";  RFX_LIB_PATH=build_var/librfx_abl.so python tools/probe_skew.py
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

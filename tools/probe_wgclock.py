@@ -2,7 +2,7 @@
 Is the tail of a Griffin-Lim launch the same workgroups every time?  (RFX_WGCLOCK build of librfx: every workgroup of every launch
 records start / end on the 100 MHz wall clock and its XCD / SE / CU.)
 
-    bash tools/build_variant.sh wgclock -DRFX_WGCLOCK        (here, no GPU needed)
+    bash tools/build_variants.sh wgclock:"-DRFX_WGCLOCK"        (here, no GPU needed)
     RFX_LIB_PATH=build_var/librfx_wgclock.so python tools/probe_wgclock.py      (on the GPU box)
 
 A launch ends when its slowest workgroup does.  If the slow workgroups were a different set each launch, one persistent launch over
