@@ -98,7 +98,9 @@ struct rfx_plan {
   int n_stft;
   int gl_wgs_per_cu = 1;    // resident Griffin-Lim workgroups per CU on this device (occupancy query at creation)
   // how much longer the run of a first-dispatched workgroup is than the mean (per mille; its CU partner's is that much shorter):
-  // rfx_kernels.h GlArgs::run_w1.  [0]: the synthesis-only launch (MODE 0), [1]: the iterations.  Measured optimum on MI355X.
+  // rfx_kernels.h GlArgs::run_w1.  [0]: the synthesis-only launch (MODE 0), [1]: the iterations.  0 = equal runs, the default:
+  // a skew of 100 makes the pair of a CU finish together and gains 0.4 % (the kernel is power-bound: DESIGN.md 4.1,
+  // profiles/r05_wgclock_dispatch_order.txt); only -DRFX_ABLATION builds can set it (RFX_GL_SKEW / RFX_GL_SKEW0).
   int gl_run_skew[2] = {RFX_GL_RUN_SKEW0, RFX_GL_RUN_SKEW};
   int imel_variant = 0;     // debugging override read once at creation: 0 = best, 1 = uniform groups, 2 = general
   unsigned long long* timing = nullptr;  // RFX_TIMING builds only
@@ -540,9 +542,41 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
           }
           return true;
         };
+        // weights as a LINE per group: on a uniform bin grid a triangular filter's weight is linear in the bin index between two
+        // centres, w0 = a0 + s0 i, w1 = a1 + s1 i for the group's i-th bin (least-squares line in double, checked per bin).  The
+        // tolerance is RELATIVE to the group's largest weight (an area-normalised bank has weights ~1e-2: an absolute 1e-6 would
+        // admit 1e-4 relative there).  Measured on the reference's banks (tests/test_round5_cpu.py): 0.72e-7 of the group maximum
+        // for htk / no norm, 1.16e-7 for slaney - one ulp of the largest weight; 4e-7 leaves a factor of three.
+        // line_from = the lowest group from which every group is a line (group 0 of a bank whose first filter rises over several
+        // bins holds that rising edge AND its own falling one: a kink)
+        lin.assign(4 * (size_t)M, 0.f);
+        int line_from = 0;
+        for (int g2 = 0; g2 < M; ++g2) {
+          const int n = cnt[g2], f0 = grp_start[g2];
+          if (n == 0) continue;
+          for (int which = 0; which < 2; ++which) {
+            const std::vector<float>& w = which ? bin_w1 : bin_w0;
+            double sx = 0, sy = 0, sxx = 0, sxy = 0;
+            for (int i = 0; i < n; ++i) { sx += i; sy += w[f0 + i]; sxx += (double)i * i; sxy += (double)i * w[f0 + i]; }
+            const double den = n * sxx - sx * sx;
+            const double slope = n > 1 ? (n * sxy - sx * sy) / den : 0.0, icpt = (sy - slope * sx) / n;
+            const float af = (float)icpt, sf = (float)slope;
+            double wmax = 0;
+            for (int i = 0; i < n; ++i) wmax = fmax(wmax, fabs((double)w[f0 + i]));
+            for (int i = 0; i < n; ++i)
+              if (fabs((double)af + (double)sf * i - (double)w[f0 + i]) > 4e-7 * wmax) line_from = g2 + 1;
+            lin[(size_t)(2 * which) * M + g2] = af;
+            lin[(size_t)(2 * which + 1) * M + g2] = sf;
+          }
+        }
         const int uni_lo[4] = {8, 8, 8, 8}, uni_hi[4] = {24, 24, 24, 24};
-        // per-wave budgets of imel_group_kernel_perwave (rfx_kernels.h): the default bank's exact set, then the wide set
-        fast_code = fits(rfx::kImelLoCap, rfx::kImelHiCap) ? 2 : fits(rfx::kImelLoCapWide, rfx::kImelHiCapWide) ? 3 : fits(uni_lo, uni_hi) ? 1 : 0;
+        // per-wave budgets of imel_group_kernel_perwave (rfx_kernels.h): the default bank's exact set, then the wide set; banks
+        // whose groups are too long for either (max_frequency above ~11 kHz at 512 filters - the reference's own round-trip test
+        // uses 20 Hz .. 20 kHz, test/spectrogram_converter_test.py:46-53 - or fewer filters) take the line-form group kernel
+        // (round 5: imel_line_kernel_perwave, code 5) when their LONG groups M-256 .. M-1 are lines; they ran on the general LDS
+        // kernel until then: 169 ms per 64 tiles against 4.5 for the default bank
+        const bool line_set = line_from <= (M > 256 ? M - 256 : 0) && fits(rfx::kImelLoCapLine, rfx::kImelHiCapLine);
+        fast_code = fits(rfx::kImelLoCap, rfx::kImelHiCap) ? 2 : fits(rfx::kImelLoCapWide, rfx::kImelHiCapWide) ? 3 : line_set ? 5 : fits(uni_lo, uni_hi) ? 1 : 0;
         fast = fast_code != 0;
         // unit form of the gradient (rfx_imel.hip): the long groups M-256 .. M-1 must have w0 + w1 == 1 per bin (triangular
         // filters, no area normalisation), the last one w1 == 0 throughout (there is no filter M)
@@ -554,36 +588,13 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
           else unit_form = fabsf(bin_w0[f] + bin_w1[f] - 1.f) <= 1e-6f;
         }
         // wave kernel (rfx_imel.hip::imel_wave_kernel): 512 groups dealt to 64 lanes in eight chunks whose budgets must hold every
-        // group, weights linear in the bin index inside a group (least-squares line in double, checked per bin); with the unit form
-        // (no area normalisation) the upper four chunks need one weight only
-        wave_ok = RFX_IMEL_WAVE && opt.imel_form == RFX_IMEL_FORM_AUTO && fast_code == 2 && M == 64 * rfx::kImelWaveChunks;
+        // group, every group a line; with the unit form (no area normalisation) the upper four chunks need one weight only
+        wave_ok = RFX_IMEL_WAVE && opt.imel_form == RFX_IMEL_FORM_AUTO && fast_code == 2 && M == 64 * rfx::kImelWaveChunks && line_from == 0;
         for (int c = 0; c < rfx::kImelWaveChunks && wave_ok; ++c)
           for (int lane = 0; lane < 64; ++lane) {
             const int n = cnt[rfx::imel_wave_group(c, lane)];
             if (n > 2 * rfx::kImelWavePairs[c] || n < 2 * rfx::kImelWaveFullPairs[c]) wave_ok = false;
           }
-        lin.assign(4 * (size_t)M, 0.f);
-        for (int g2 = 0; g2 < M && wave_ok; ++g2) {
-          const int n = cnt[g2], f0 = grp_start[g2];
-          if (n == 0) continue;
-          for (int which = 0; which < 2; ++which) {
-            const std::vector<float>& w = which ? bin_w1 : bin_w0;
-            double sx = 0, sy = 0, sxx = 0, sxy = 0;
-            for (int i = 0; i < n; ++i) { sx += i; sy += w[f0 + i]; sxx += (double)i * i; sxy += (double)i * w[f0 + i]; }
-            const double den = n * sxx - sx * sx;
-            const double slope = n > 1 ? (n * sxy - sx * sy) / den : 0.0, icpt = (sy - slope * sx) / n;
-            const float af = (float)icpt, sf = (float)slope;
-            // tolerance RELATIVE to the group's largest weight (an area-normalised bank has weights ~1e-2: an absolute 1e-6 would
-            // admit 1e-4 relative there).  Measured on the reference's banks (tools/probe_line_fit.py): 0.72e-7 of the group
-            // maximum for htk / no norm, 1.16e-7 for slaney - one ulp of the largest weight; 4e-7 leaves a factor of three.
-            double wmax = 0;
-            for (int i = 0; i < n; ++i) wmax = fmax(wmax, fabs((double)w[f0 + i]));
-            for (int i = 0; i < n; ++i)
-              if (fabs((double)af + (double)sf * i - (double)w[f0 + i]) > 4e-7 * wmax) wave_ok = false;
-            lin[(size_t)(2 * which) * M + g2] = af;
-            lin[(size_t)(2 * which + 1) * M + g2] = sf;
-          }
-        }
       }
     }
     pl->imel_ok = ok;
@@ -711,7 +722,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       memcpy(&blob[o_p], bin_pos.data(), F * 4);
       memcpy(&blob[o_p2], bin_pos2.data(), F * 4);
       memcpy(&blob[o_gs], grp_start.data(), (M + 1) * 4);
-      if (fast && wave_ok) memcpy(&blob[o_lin], lin.data(), 4 * (size_t)M * 4);
+      if (fast && lin.size() == 4 * (size_t)M) memcpy(&blob[o_lin], lin.data(), 4 * (size_t)M * 4);
       RFX_HIP(hipMalloc(&pl->d_imel_blob, off));
       RFX_HIP(hipMemcpy(pl->d_imel_blob, blob.data(), off, hipMemcpyHostToDevice));
       char* d = (char*)pl->d_imel_blob;

@@ -686,6 +686,192 @@ __device__ __forceinline__ void wv_store(const WvChunk<NP, NF, UF>& k, int g, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Line form inside the group-kernel layout (round 5).  The wave kernel above serves ONE bank shape (512 groups whose sizes fit its
+// chunk budgets: the default 0 - 10 kHz bank); every bank with longer groups - 512 filters up to 16 / 20 / 22.05 kHz (the
+// reference's own round-trip test runs 20 Hz .. 20 kHz, test/spectrogram_converter_test.py:46-53), 384 filters - fell through to
+// the general LDS kernel: 169 ms per 64 tiles against 4.5.  The group kernels cannot take them either: with four registers per
+// bin (spec, buffer, two weights) a 62-bin group does not fit a thread.  Here a thread keeps the group kernels' roles and LDS
+// exchange (short group t, long group M-1-t; A and B published, one barrier per step, residuals formed from the neighbours'
+// sums) but holds its LONG group in the wave kernel's line form - weights a0 + s0 i, momentum buffer C + G i, ONE register per
+// bin plus a 0 / 1 mask per slot (group sizes vary inside a wave's class, and in unit form B = S - A must not see a padding slot) -
+// while the short group stays in table form (group 0 of a bank may hold its first filter's rising edge and is not a line).
+// The plan admits the kernel when the long groups M-256 .. M-1 are lines (rfx_api.hip, code 5) and the budgets kImelLoCapLine /
+// kImelHiCapLine hold every group.  Two waves per SIMD (the heaviest class holds 31 spec pairs + 31 masks).
+template <int NP, bool UF>
+struct LineGroup {
+  c2 spec[NP], mask[NP];
+  float a0, s0, a1, s1;  // a1, s1 unused in unit form
+  float C, G;            // the momentum buffer of the group's bin i is C + G i, in units of the STEP
+};
+template <int NP, bool UF>
+__device__ __forceinline__ void line_load(LineGroup<NP, UF>& k, int g, const ImelArgs& a, int frame, unsigned rbase) {
+  const ImelTables& tb = a.tb;
+  const int f0 = g >= 0 ? tb.grp_start[g] : 0, n = g >= 0 ? tb.grp_start[g + 1] - f0 : 0;
+  k.a0 = g >= 0 ? tb.lin[g] : 0.f;
+  k.s0 = g >= 0 ? tb.lin[a.M + g] : 0.f;
+  k.a1 = g >= 0 ? tb.lin[2 * a.M + g] : 0.f;
+  k.s1 = g >= 0 ? tb.lin[3 * a.M + g] : 0.f;
+  k.C = 0.f;
+  k.G = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2 * NP; ++i) {
+    const bool ok = i < n;
+    const int f = f0 + (ok ? i : 0);
+    const float sp = ok ? kImelScale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
+    if (i & 1) { k.spec[i >> 1].y = sp; k.mask[i >> 1].y = ok ? 1.f : 0.f; }
+    else       { k.spec[i >> 1].x = sp; k.mask[i >> 1].x = ok ? 1.f : 0.f; }
+  }
+}
+// A = sum w0 x = a0 S + s0 Q with S = sum x_i, Q = sum i x_i (four accumulator chains); B likewise, or S - A in unit form
+template <int NP, bool UF>
+__device__ __forceinline__ void line_ab(const LineGroup<NP, UF>& k, float& A, float& B) {
+  static_assert(NP >= 2, "a line group holds at least two pairs");
+  c2 Sa = k.spec[0], Sb = k.spec[1], Qa = bc2(0.f), Qb = k.spec[1];
+#pragma unroll
+  for (int p = 2; p < NP; ++p) {
+    if (p & 1) { Sb = Sb + k.spec[p]; Qb = __builtin_elementwise_fma(bc2((float)p), k.spec[p], Qb); }
+    else       { Sa = Sa + k.spec[p]; Qa = __builtin_elementwise_fma(bc2((float)p), k.spec[p], Qa); }
+  }
+  const c2 S = Sa + Sb, Q = Qa + Qb;
+  const float s = S.x + S.y, h = Q.x + Q.y;
+  const float q = fmaf(2.f, h, S.y);  // sum i x_i over the slots (2p, 2p + 1) = 2 sum p (x_2p + x_2p+1) + sum x_2p+1
+  A = fmaf(k.s0, q, k.a0 * s);
+  B = UF ? s - A : fmaf(k.s1, q, k.a1 * s);
+}
+// n0, n1: the residuals of the group's two filters times the step factor -lr g.  Gradient line cc + st i, buffer line (C, G) updated
+// like torch.optim.SGD's buf.mul_(momentum).add_(grad), then x = clamp(x + mask (C + G i)) pair by pair
+template <int NP, bool UF>
+__device__ __forceinline__ void line_step(LineGroup<NP, UF>& k, float n0, float n1, float mom) {
+  float cc, st;
+  if (UF) {
+    const float dd = n0 - n1;
+    cc = fmaf(dd, k.a0, n1);
+    st = dd * k.s0;
+  } else {
+    cc = fmaf(n1, k.a1, n0 * k.a0);
+    st = fmaf(n1, k.s1, n0 * k.s0);
+  }
+  k.C = fmaf(mom, k.C, cc);
+  k.G = fmaf(mom, k.G, st);
+  const c2 base = c2{k.C, k.C + k.G}, s2 = bc2(k.G + k.G);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const c2 v = p == 0 ? base : __builtin_elementwise_fma(bc2((float)p), s2, base);
+    k.spec[p] = pk_fma_clamp(k.spec[p], v, k.mask[p]);
+  }
+}
+template <int NP, bool UF>
+__device__ __forceinline__ void line_store(const LineGroup<NP, UF>& k, int g, const ImelTables& tb, float* out) {
+  if (g < 0) return;
+  const int f0 = tb.grp_start[g], n = tb.grp_start[g + 1] - f0;
+#pragma unroll
+  for (int i = 0; i < 2 * NP; ++i)
+    if (i < n) {
+      const int f = f0 + i;
+      const float v = kImelUnscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
+      out[tb.bin_pos[f]] = v;
+      const int p2 = tb.bin_pos2[f];
+      if (p2 >= 0) out[p2] = v;
+    }
+}
+
+// the group body (imel_group_body) with the long group in line form; same roles, same LDS layout, same barriers
+template <int NLO, int NHI, bool UF>
+__device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, int tid, int frame) {
+  const ImelTables& tb = a.tb;
+  const int M = a.M;
+  float* Ab = reinterpret_cast<float*>(smem);  // [2][M + 4], entry m at index m + 1
+  float* Bb = Ab + 2 * (M + 4);                // [2][M + 4]
+  float* part = Bb + 2 * (M + 4);              // [max_iter][4] per-wave partial sums of diff^2
+  const int b = frame / a.T, t = frame - b * a.T;
+  const int clip = b / a.C;
+  const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
+  if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
+  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
+  const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;
+  const int gL = (tid < M - kImelThreads) ? tid : -1;
+  GroupState<NLO, false> lo;
+  LineGroup<(NHI + 1) / 2, UF> hi;
+  group_load(lo, gL, a, frame, rbase, kImelScale);
+  line_load(hi, gH, a, frame, rbase);
+  auto melat = [&](int m) { return (m >= 0 && m < M) ? kImelScale * a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
+  const float mL0 = gL >= 0 ? melat(gL) : 0.f, mL1 = gL >= 0 ? melat(gL + 1) : 0.f;
+  const float mH0 = gH >= 0 ? melat(gH) : 0.f, mH1 = gH >= 0 ? melat(gH + 1) : 0.f;
+  for (int i = tid; i < 4 * (M + 4); i += kImelThreads) Ab[i] = 0.f;
+  const float lrg = a.lr * (-2.0f / (float)(a.C * a.T));
+  const float nl = -lrg;  // the step in units of the gradient scale (see imel_group_body)
+  const unsigned nlb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, nl));
+  const unsigned long long nl2 = ((unsigned long long)nlb << 32) | nlb;
+  const int xL = (gL >= 0 ? gL : M + 1) + 1, xH = (gH >= 0 ? gH : M + 1) + 1;
+  const bool noH1 = UF && gH == M - 1;
+  const int wave = tid >> 6;
+  __syncthreads();
+
+  auto sgd_step = [&](int it, float* __restrict__ Ap, float* __restrict__ Bp) {
+    float AL, BL, AH, BH;
+    group_ab(lo, AL, BL);
+    line_ab(hi, AH, BH);
+    Ap[xL] = AL; Bp[xL] = BL;
+    Ap[xH] = AH; Bp[xH] = BH;
+    __syncthreads();
+    const float bLm = Bp[xL - 1], aLp = Ap[xL + 1], bHm = Bp[xH - 1], aHp = Ap[xH + 1];
+    const float dL0 = mL0 - AL - bLm;
+    const float dL1 = mL1 - aLp - BL;
+    const float dH0 = mH0 - AH - bHm;
+    const float dH1 = noH1 ? 0.f : mH1 - aHp - BH;
+    const float uL = kImelUnscale * dL0, uH = kImelUnscale * dH0;
+    const float sq = wave_sum(fmaf(uL, uL, uH * uH));
+    if ((tid & 63) == 0) part[4 * it + wave] = sq;
+    group_step(lo, dL0, dL1, a.momentum, nl2);
+    line_step(hi, nl * dH0, nl * dH1, a.momentum);
+  };
+  float* const A0 = Ab, * const A1 = Ab + (M + 4), * const B0 = Bb, * const B1 = Bb + (M + 4);
+  int it = 0;
+  for (; it + 1 < steps; it += 2) {
+    sgd_step(it, A0, B0);
+    sgd_step(it + 1, A1, B1);
+  }
+  if (it < steps) sgd_step(it, A0, B0);
+  __syncthreads();
+
+  float* out = a.out_slots + (size_t)frame * a.out_stride;
+  group_store(lo, tb, out, kImelUnscale);
+  line_store(hi, gH, tb, out);
+  for (int f = tid; f < a.n_stft; f += kImelThreads) {
+    if (f >= tb.f_lo && f < tb.f_hi) continue;
+    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f);
+    out[tb.bin_pos[f]] = v;
+    const int p2 = tb.bin_pos2[f];
+    if (p2 >= 0) out[p2] = v;
+  }
+  if (a.plain) {
+    for (int p = a.n_stft + tid; p < a.out_stride; p += kImelThreads) out[p] = 0.f;
+  } else {
+    for (int p = tid; p < kFrameStride; p += kImelThreads) {
+      int q, kb;
+      if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
+    }
+  }
+  if (a.loss_hist && !a.it_limit)
+    for (int i = tid; i < a.max_iter; i += kImelThreads)
+      a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]) : 0.f;
+}
+
+template <bool UF, int L0, int H0, int L1, int H1, int L2, int H2, int L3, int H3>
+__global__ void __launch_bounds__(kImelThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) imel_line_kernel_perwave(ImelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cls = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = threadIdx.x;
+  const int frame = blockIdx.x;
+  switch (cls) {
+    case 0: imel_line_body<L0, H0, UF>(a, smem, tid, frame); break;
+    case 1: imel_line_body<L1, H1, UF>(a, smem, tid, frame); break;
+    case 2: imel_line_body<L2, H2, UF>(a, smem, tid, frame); break;
+    default: imel_line_body<L3, H3, UF>(a, smem, tid, frame); break;
+  }
+}
+
 #define RFX_WV_CHUNKS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define RFX_WV_LO(X) X(0) X(1) X(2) X(3)
 #define RFX_WV_HI(X) X(4) X(5) X(6) X(7)
@@ -888,7 +1074,17 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
     return hipGetLastError();
   }
 #endif
-  if (a.tb.fast_ok && variant != 2 && !(variant == 1 && a.tb.fast_ok == 3)) {  // (the wide set has no uniform fallback: general kernel)
+#if RFX_IMEL_PK
+  if (a.tb.fast_ok == 5 && variant == 0) {  // long groups in line form (full-band banks, 384 filters ...)
+    constexpr const int* lo = kImelLoCapLine;
+    constexpr const int* hi = kImelHiCapLine;
+    const size_t lds = imel_group_lds_bytes(a.M, a.max_iter);
+    if (a.tb.unit_form) hipLaunchKernelGGL((imel_line_kernel_perwave<true, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
+    else hipLaunchKernelGGL((imel_line_kernel_perwave<false, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
+    return hipGetLastError();
+  }
+#endif
+  if (a.tb.fast_ok && a.tb.fast_ok != 5 && variant != 2 && !(variant == 1 && a.tb.fast_ok == 3)) {  // (the wide and line sets have no uniform fallback: general kernel)
     // the fix-up pass runs a different number of steps (and barriers) per clip: one frame per workgroup there
     const bool fixup = a.it_limit != nullptr;
     if (a.tb.fast_ok == 2 && variant != 1) {

@@ -135,6 +135,11 @@ constexpr int kImelHiCap[4] = {23, 16, 12, 9};
 // so its low groups are longer, and its top groups reach 26 bins)
 constexpr int kImelLoCapWide[4] = {5, 3, 5, 6};
 constexpr int kImelHiCapWide[4] = {26, 17, 12, 9};
+// a third set (round 5) for the LINE-FORM group kernel (rfx_imel.hip::imel_line_kernel_perwave): the long groups keep one register
+// per bin (weights and momentum buffer are lines per group), so a thread can hold 62 of them - 512 filters up to the Nyquist
+// frequency (group sizes 1.5 .. 61 bins), htk or slaney scale, or 256 / 384 filters over the default 0 - 10 kHz
+constexpr int kImelLoCapLine[4] = {6, 5, 7, 11};
+constexpr int kImelHiCapLine[4] = {62, 40, 26, 18};
 // Wave kernel (round 4, rfx_imel.hip::imel_wave_kernel): ONE wave per frame.  The 512 groups are dealt to the 64 lanes in eight
 // chunks of 64 consecutive groups, even chunks in lane order and odd chunks reversed (group 64 c + lane / 64 c + 63 - lane), so a
 // lane's bin count is within 4 % of the mean although group sizes grow 12-fold over the bank, and every group's neighbours sit
@@ -163,7 +168,7 @@ struct ImelTables {
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
   int nnz;
   int fast_ok;           // 0: general kernel; 1: group formulation with <8, 24> bins per thread; 2: per-wave budgets (default set) fit too;
-                         // 3: only the wide per-wave set fits
+                         // 3: only the wide per-wave set fits; 5: the line-form group kernel's set (long groups as lines)
   int unit_form;         // 1: in every long group (the top 256) a bin's two weights sum to one (to 1e-6) - the last group, whose second
                          // filter does not exist, carries w1 == 0: the per-wave kernels compute the gradient as d1 + (d0 - d1) w0
   const float* lin;      // [4][M] a0 | s0 | a1 | s1: within group g the weights are w0 = a0 + s0 i, w1 = a1 + s1 i for the group's i-th bin

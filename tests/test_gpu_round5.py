@@ -86,3 +86,36 @@ def test_runs_that_cross_clip_boundaries_against_the_oracle(plan, O, B, Tn):
     # a seam handled wrongly leaves a clip at 10 - 30 dB; one ill-conditioned bin (tests/helpers.py::mask_ill_conditioned_bins) can
     # cost a 22-frame clip up to 10 log10(F T / 12) = 42 dB, so the per-clip floor is 45 dB and the tight gates are the batch and the median
     assert got.shape == want.shape and snr_db(want, got) >= 95.0 and float(np.median(per_clip)) >= 100.0 and min(per_clip) >= 45.0
+
+
+@pytest.mark.parametrize("kw,unit", [(dict(min_frequency=20, max_frequency=20000), 1), (dict(max_frequency=22050), 1), (dict(max_frequency=16000, mel_scale_norm="slaney"), 0),
+                                     (dict(max_frequency=20000, mel_scale_type="slaney"), 1), (dict(num_frequencies=384), 1)])
+def test_line_form_group_kernel_on_banks_with_long_groups(O, kw, unit):
+    """Banks whose groups are too long for the group kernels' register budgets (512 filters up to 16 / 20 / 22.05 kHz - the reference's
+    own round-trip test runs 20 Hz .. 20 kHz, test/spectrogram_converter_test.py:46-53 - or 384 filters) ran on the general LDS kernel
+    until round 5 (169 ms per 64 tiles); they take the line-form group kernel now (rfx_plan_imel_kernel 5).  Against the oracle after
+    the reference's 200 steps, injected start, stereo coupling and a frame count that fills no workgroup slot evenly; the same bank on
+    the general kernel (rfx_plan_options.imel_form has no switch for it: the uniform variant of an ablation build would be needed) is
+    covered by test_inverse_mel_other_parameter_sets_use_fallback_kernels' history: here the oracle is the judge."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    p = SpectrogramParams(**kw)
+    op = O.params_from(p)
+    plan = _hip.get_plan(p, "cuda")
+    assert plan.lib.rfx_plan_imel_kernel(plan.handle) == 5 and plan.lib.rfx_plan_imel_unit_form(plan.handle) == unit
+    T, C = 9, 2
+    g = torch.Generator().manual_seed(len(str(kw)))
+    mel = torch.rand(C, p.num_frequencies, T, generator=g) ** 3 * 2e7
+    spec0 = torch.rand(C, T, op.n_stft, generator=g)
+    ref = O.inverse_mel_scale_sgd(mel, op, spec0=spec0)
+    got = plan.unpack_magnitudes(plan.inverse_mel(mel.cuda(), C, spec0=spec0.cuda()), C, T).cpu()
+    active = O.mel_filterbank(op).abs().sum(1) > 0
+    rel = float(torch.linalg.norm(got[:, active] - ref[:, active]) / torch.linalg.norm(ref[:, active]))
+    print(f"{kw}: line-form group kernel vs oracle after 200 steps: rel-L2 {rel:.2e} on {int(active.sum())} active bins")
+    assert rel <= 1e-5  # measured ~1e-7; the family-wide gate is 1e-3
+    assert torch.equal(got[:, ~active], spec0.transpose(1, 2)[:, ~active])
+    # drawn start: finite, non-negative, and a different seed gives different magnitudes
+    a = plan.unpack_magnitudes(plan.inverse_mel(mel.cuda(), C, seed=1), C, T)
+    b = plan.unpack_magnitudes(plan.inverse_mel(mel.cuda(), C, seed=2), C, T)
+    assert bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0 and not torch.equal(a, b)
