@@ -930,6 +930,46 @@ def main():
             dtb = (time.perf_counter() - tb) / 3
             sweep[str(Bs)] = {"tiles_per_s": round(Bs / dtb, 1), "ms_per_step": round(dtb * 1e3, 3)}
             del tl, ws
+        # ---- the reference's own round-trip test parameters (test/spectrogram_converter_test.py:46-53: 20 Hz .. 20 kHz, 512 filters):
+        # groups of up to 54 bins - InverseMelScale ran on the general LDS kernel (169 ms per 64 tiles) until round 5's line-form
+        # group kernel; the decode step of 64 mono tiles and the forward path with that bank
+        p_fb = SpectrogramParams(min_frequency=20, max_frequency=20000, num_griffin_lim_iters=args.iters)
+        plan_fb = _hip.get_plan(p_fb, dev)
+        lut_fb = torch.from_numpy(image_util.decode_lut(0.25, 30e6)).to(dev)
+
+        def step_fb(seed):
+            m_ = plan_fb.image_decode(tiles, False, lut_fb)
+            l_ = plan_fb.inverse_mel(m_, 1, seed=seed)
+            w_ = plan_fb.griffinlim(l_, B, T, args.iters, 0.99, seed=seed + 1)
+            return plan_fb.pcm16(w_, channels=1, normalize=True)[0], m_
+
+        _, mel_fb = step_fb(0)
+        torch.cuda.synchronize(dev)
+        tfb = time.perf_counter()
+        for k in range(3):
+            pcm_fb, _ = step_fb(3 + k)
+        torch.cuda.synchronize(dev)
+        dtfb = (time.perf_counter() - tfb) / 3
+        efb = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        efb[0].record()
+        plan_fb.inverse_mel(mel_fb, 1, seed=9)
+        efb[1].record()
+        torch.cuda.synchronize(dev)
+        wave_fb = torch.randn(B, HOP * (T - 1), device=dev) * 8000
+        plan_fb.mel_from_waveform(wave_fb)
+        efw = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        efw[0].record()
+        for _ in range(5):
+            plan_fb.mel_from_waveform(wave_fb)
+        efw[1].record()
+        torch.cuda.synchronize(dev)
+        other_cfg["full_band_20hz_20khz"] = {
+            "tiles_per_s": round(B / dtfb, 1), "ms_per_step": round(dtfb * 1e3, 3), "steps": 3, "inverse_mel_ms": round(efb[0].elapsed_time(efb[1]), 3),
+            "forward_mel_ms": round(efw[0].elapsed_time(efw[1]) / 5, 3),
+            "inverse_mel_kernel": int(plan_fb.lib.rfx_plan_imel_kernel(plan_fb.handle)), "finite": bool(torch.isfinite(pcm_fb.float()).all()),
+            "workload": f"batch={B} synthetic 512x512 mono uint8 tiles -> audio with min_frequency=20, max_frequency=20000 (the reference's "
+                        f"round-trip test parameters), Griffin-Lim {args.iters}; inverse_mel_kernel 5 = line-form group kernel, 0 = general LDS kernel"}
+        del plan_fb, mel_fb, pcm_fb, wave_fb
         for Bs in (65, 96, 100):  # distance from the straight line between B = 64 and B = 128 (the run partition has no cliff: <= 5 %)
             line = sweep["64"]["ms_per_step"] + (sweep["128"]["ms_per_step"] - sweep["64"]["ms_per_step"]) * (Bs - 64) / 64.0
             sweep[str(Bs)]["vs_linear_64_128_pct"] = round(100.0 * (sweep[str(Bs)]["ms_per_step"] / line - 1.0), 2)

@@ -198,10 +198,12 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
 /* which SGD kernel rfx_inverse_mel runs for this plan's filterbank: 4 = wave kernel (one wave per frame, weights as a line per
  * group: the default 512-filter HTK bank, with or without slaney normalisation), 2 = group kernel with per-wave register budgets sized to
  * the default 512-filter HTK bank (with or without slaney normalisation), 3 = the same kernel with the wider budget set
- * (mel_scale_type "slaney"), 1 = group kernel with a uniform budget (other banks whose groups fit 8 / 24 bins),
+ * (mel_scale_type "slaney"), 5 = line-form group kernel (round 5: banks with groups of up to 62 bins whose long groups are lines -
+ * 512 filters up to the Nyquist frequency, e.g. the 20 Hz .. 20 kHz of the reference's test/spectrogram_converter_test.py:46-53,
+ * or 256 / 384 filters over 0 - 10 kHz), 1 = group kernel with a uniform budget (other banks whose groups fit 8 / 24 bins),
  * 0 = general LDS kernel (any banded bank), -1 = not banded (rfx_inverse_mel refuses) */
 int rfx_plan_imel_kernel(const rfx_plan* plan);
-/* 1 when that kernel (2 or 3) computes a bin's gradient in unit form, d1 + (d0 - d1) w0: valid when the two weights of every
+/* 1 when that kernel (2, 3, 4 or 5) computes a bin's gradient in unit form, d1 + (d0 - d1) w0: valid when the two weights of every
  * bin of the long groups sum to one, i.e. triangular filters without area normalisation (mel_scale_norm None); 0 = both
  * weights are multiplied out (mel_scale_norm "slaney", other kernels) */
 int rfx_plan_imel_unit_form(const rfx_plan* plan);

@@ -519,6 +519,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     bool fast = ok && M <= 512;
     int fast_code = 0;
     bool unit_form = false, wave_ok = false;
+    int line_from_out = 0;  // groups below it are not lines (rfx_kernels.h, ImelTables::line_from)
     std::vector<float> lin;
     if (fast) {
       int prev = 0;
@@ -575,7 +576,20 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
         // uses 20 Hz .. 20 kHz, test/spectrogram_converter_test.py:46-53 - or fewer filters) take the line-form group kernel
         // (round 5: imel_line_kernel_perwave, code 5) when their LONG groups M-256 .. M-1 are lines; they ran on the general LDS
         // kernel until then: 169 ms per 64 tiles against 4.5 for the default bank
-        const bool line_set = line_from <= (M > 256 ? M - 256 : 0) && fits(rfx::kImelLoCapLine, rfx::kImelHiCapLine);
+        // (a long group that is NOT a line - group 0 of a bank with at most 256 filters - moves into its thread's free table-form slot)
+        auto fits_line = [&]() {
+          for (int t2 = 0; t2 < 256; ++t2) {
+            const int gH = M - 1 - t2, gL = t2 < M - 256 ? t2 : -1, c = t2 >> 6;
+            if (gH >= 0 && gH < line_from) {
+              if (gL >= 0 || cnt[gH] > rfx::kImelLoCapLine[c]) return false;
+            } else if (gH >= 0 && cnt[gH] > rfx::kImelHiCapLine[c]) return false;
+            if (gL >= 0 && cnt[gL] > rfx::kImelLoCapLine[c]) return false;
+            if (gL >= 0 && gH >= 0 && gL >= gH) return false;
+          }
+          return true;
+        };
+        const bool line_set = fits_line();
+        line_from_out = line_from;
         fast_code = fits(rfx::kImelLoCap, rfx::kImelHiCap) ? 2 : fits(rfx::kImelLoCapWide, rfx::kImelHiCapWide) ? 3 : line_set ? 5 : fits(uni_lo, uni_hi) ? 1 : 0;
         fast = fast_code != 0;
         // unit form of the gradient (rfx_imel.hip): the long groups M-256 .. M-1 must have w0 + w1 == 1 per bin (triangular
@@ -739,6 +753,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->imel.unit_form = fast && unit_form ? 1 : 0;
       pl->imel.lin = (const float*)(d + o_lin);
       pl->imel.wave_ok = fast && wave_ok ? 1 : 0;
+      pl->imel.line_from = line_from_out;
       pl->imel.f_lo = f_lo;
       pl->imel.f_hi = f_hi;
       pl->imel.nnz = (int)nnz;

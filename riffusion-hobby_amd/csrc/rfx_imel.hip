@@ -789,8 +789,12 @@ __device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, in
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
   const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
-  const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;
-  const int gL = (tid < M - kImelThreads) ? tid : -1;
+  int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;
+  int gL = (tid < M - kImelThreads) ? tid : -1;
+  if (gH >= 0 && gH < tb.line_from) {  // a long group that is not a line: into the (free: the plan checked) table-form slot
+    gL = gH;
+    gH = -1;
+  }
   GroupState<NLO, false> lo;
   LineGroup<(NHI + 1) / 2, UF> hi;
   group_load(lo, gL, a, frame, rbase, kImelScale);

@@ -173,6 +173,8 @@ struct ImelTables {
                          // filter does not exist, carries w1 == 0: the per-wave kernels compute the gradient as d1 + (d0 - d1) w0
   const float* lin;      // [4][M] a0 | s0 | a1 | s1: within group g the weights are w0 = a0 + s0 i, w1 = a1 + s1 i for the group's i-th bin
                          // (triangular filters on a uniform bin grid; fitted and checked to 1e-6 per bin at plan creation)
+  int line_from;         // groups below this index are NOT lines (group 0 of a bank whose first filter rises over several bins): the
+                         // line-form group kernel keeps such a long group in its thread's table-form slot
   int wave_ok;           // 1: imel_wave_kernel serves this bank (M == 512, the chunk budgets fit, the weights are linear per group)
 };
 struct ImelArgs {

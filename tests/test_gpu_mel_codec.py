@@ -279,10 +279,10 @@ def test_stereo_tiles_64_iterations_end_to_end(O):
     assert snr_db(ref, got) >= 40.0  # >= 40 dB at 64 iterations
 
 
-@pytest.mark.parametrize("kw", [dict(min_frequency=20, max_frequency=20000), dict(num_frequencies=256)])
+@pytest.mark.parametrize("kw", [dict(min_frequency=20, max_frequency=20000), dict(num_frequencies=256), dict(num_frequencies=128)])
 def test_inverse_mel_other_parameter_sets_use_fallback_kernels(O, kw):
     """Mel parameters outside the default bank's register budgets: 20 Hz .. 20 kHz takes the line-form group kernel since round 5
-    (tests/test_gpu_round5.py), 256 filters (group 0 holds the first filter's rising edge and is not a line) the general banded kernel."""
+    (tests/test_gpu_round5.py), so do 256 filters; 128 filters (groups of up to 90 bins) the general banded kernel."""
     from riffusion import _hip
     from riffusion.spectrogram_params import SpectrogramParams
 
