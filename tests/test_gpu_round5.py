@@ -92,7 +92,9 @@ def test_runs_that_cross_clip_boundaries_against_the_oracle(plan, O, B, Tn):
                                      (dict(max_frequency=20000, mel_scale_type="slaney"), 1), (dict(num_frequencies=384), 1),
                                      # 256 filters: every group is a long one, and group 0 holds the first filter's rising edge next to its
                                      # falling one - not a line: it sits in its thread's table-form slot (and the unit form is off)
-                                     (dict(num_frequencies=256), 0), (dict(num_frequencies=300, max_frequency=12000), 1)])
+                                     (dict(num_frequencies=256), 0), (dict(num_frequencies=300, max_frequency=12000), 1),
+                                     # 200 filters: 56 thread roles own nothing; 48 kHz: the generic plan's plain bin-ordered frames
+                                     (dict(num_frequencies=200), 0), (dict(sample_rate=48000, max_frequency=20000), 1)])
 def test_line_form_group_kernel_on_banks_with_long_groups(O, kw, unit):
     """Banks whose groups are too long for the group kernels' register budgets (512 filters up to 16 / 20 / 22.05 kHz - the reference's
     own round-trip test runs 20 Hz .. 20 kHz, test/spectrogram_converter_test.py:46-53 - or 384 filters) ran on the general LDS kernel
