@@ -129,6 +129,7 @@ struct rfx_plan {
   int* d_slot_idx = nullptr;       // ... [kMelPadsPerThread][kQPad] padding positions, [2][Mpad] filter segments, [21][kQPad] product positions; null: table form
   unsigned fwd_kb_mask = 0;
   int fwd_prod_arr = 0;
+  int fwd_packed_off = 0;          // ints into d_slot_idx where the packed tables start (0: none)
   int fwd_run_cap = 64;            // longest run of frames one workgroup of the product-form kernel walks (RFX_FWD_RUN, read at creation)
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
   bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
@@ -657,11 +658,17 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
           else { prev = bin_m0[f]; cnt[prev]++; }
         }
         // (a zero row inside [f_lo, f_hi) has bin_m0 == -1 < prev and lands here as "not monotone")
-        std::vector<int> G(M + 1, 0);  // padded position of group g
+        // LDS layout in floats: [0, kQPad) one dump float per lane, [kQPad, G[M]) the w0 products group by group, then at the distance
+        // `arr` the same again for w1 - its dump floats [arr, arr + kQPad) sit behind the w0 array, its products at arr + G[g].
+        // (Rounds 3-4 put the dump floats behind both arrays: the w1 dump stores of a non-contributing slot then aimed past the cube
+        // for banks beyond 6000 padded bins and relied on the LDS range check dropping them.)
+        std::vector<int> G(M + 1, kQPad);  // padded position of group g
         for (int g2 = 0, acc = f_lo; g2 < M; ++g2) { gfirst[g2] = acc; acc += cnt[g2]; G[g2 + 1] = G[g2] + (cnt[g2] + 3) / 4 * 4; }
-        const int arr = G[M];
-        const int dump0 = 2 * arr;  // one dump float per lane behind the two arrays
-        if (v2 && dump0 + kQPad > 2 * kCubeElems) v2 = false;
+        // the packed tables of the default-bank kernel want the second array at a compile-time distance: the gap behind G[M] is never read
+        const bool packed_ok = G[M] <= kMelProdArr;
+        const int arr = packed_ok ? kMelProdArr : G[M];
+        const int dump0 = 0;
+        if (v2 && arr + G[M] + 16 > 2 * kCubeElems) v2 = false;  // (a short segment's four unconditional 16-byte reads may run 12 floats past the last group)
         // every filter must equal its two group sums exactly: check weights against the dense bank
         for (int m = 0; m < M && v2; ++m)
           for (int f = band_lo[m]; f < band_hi[m] && v2; ++f) {
@@ -704,12 +711,37 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
             seg[(size_t)Mpad + m] = (G[m] << 4) | ((cnt[m] + 3) / 4);              // falling: w0 products of group m
           }
           if (v2) {
+          // packed copies for the default-bank kernel (rfx_kernels.h: pk_at / pk_pad / pk_seg)
+          std::vector<unsigned> pk;
+          const bool packed = packed_ok && (mask & ~rfx::kKbMaskLow) == 0 && G[M] * 4 <= 65536;  // (16-bit byte addresses of the first array)
+          if (packed) {
+            pk.assign(5 * (size_t)kQPad + 2 * (size_t)kQPad + 2 * (size_t)Mpad, 0u);
+            int kbs[10], n = 0;
+            for (int kb = 0; kb < 21; ++kb)
+              if ((rfx::kKbMaskLow >> kb) & 1u) kbs[n++] = kb;
+            for (int i = 0; i < 5; ++i)
+              for (int qp = 0; qp < kQPad; ++qp)
+                pk[(size_t)i * kQPad + qp] = (unsigned)(4 * tab_at[(size_t)kbs[2 * i] * kQPad + qp]) | ((unsigned)(4 * tab_at[(size_t)kbs[2 * i + 1] * kQPad + qp]) << 16);
+            unsigned* pkpad = pk.data() + 5 * (size_t)kQPad;
+            for (int qp = 0; qp < kQPad; ++qp)
+              for (int w = 0; w < 2; ++w)
+                pkpad[2 * qp + w] = (unsigned)(4 * padtab[(size_t)(2 * w) * kQPad + qp]) | ((unsigned)(4 * padtab[(size_t)(2 * w + 1) * kQPad + qp]) << 16);
+            unsigned* pkseg = pkpad + 2 * (size_t)kQPad;
+            for (int m = 0; m < Mpad; ++m) {
+              pkseg[2 * m] = (unsigned)seg[m];
+              pkseg[2 * m + 1] = (unsigned)seg[(size_t)Mpad + m];
+            }
+          }
           RFX_HIP(hipMalloc(&pl->d_slot_tab, tab.size() * sizeof(SlotEntry)));
           RFX_HIP(hipMemcpy(pl->d_slot_tab, tab.data(), tab.size() * sizeof(SlotEntry), hipMemcpyHostToDevice));
-          RFX_HIP(hipMalloc(&pl->d_slot_idx, (padtab.size() + seg.size() + tab_at.size()) * sizeof(int)));
+          RFX_HIP(hipMalloc(&pl->d_slot_idx, (padtab.size() + seg.size() + tab_at.size() + pk.size()) * sizeof(int)));
           RFX_HIP(hipMemcpy(pl->d_slot_idx, padtab.data(), padtab.size() * sizeof(int), hipMemcpyHostToDevice));
           RFX_HIP(hipMemcpy(pl->d_slot_idx + padtab.size(), seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice));
           RFX_HIP(hipMemcpy(pl->d_slot_idx + padtab.size() + seg.size(), tab_at.data(), tab_at.size() * sizeof(int), hipMemcpyHostToDevice));
+          if (packed) {
+            RFX_HIP(hipMemcpy(pl->d_slot_idx + padtab.size() + seg.size() + tab_at.size(), pk.data(), pk.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+            pl->fwd_packed_off = (int)(padtab.size() + seg.size() + tab_at.size());
+          }
           pl->fwd_kb_mask = mask;
           pl->fwd_prod_arr = arr;
           }
@@ -1302,6 +1334,9 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     f.slot_at = plan->d_slot_idx ? f.filt_seg + 2 * (size_t)plan->Mpad : nullptr;
     f.prod_arr = plan->fwd_prod_arr;
     f.kb_mask = plan->fwd_kb_mask;
+    f.pk_at = plan->fwd_packed_off ? reinterpret_cast<const unsigned*>(plan->d_slot_idx + plan->fwd_packed_off) : nullptr;
+    f.pk_pad = f.pk_at ? f.pk_at + 5 * (size_t)kQPad : nullptr;
+    f.pk_seg = f.pk_at ? f.pk_pad + 2 * (size_t)kQPad : nullptr;
     // runs of consecutive frames: every resident workgroup slot of the chip gets one run when the batch allows it (the
     // product-form kernel carries a sliding input window along a run), at most 64 frames, at least 1
     const long long frames = (long long)B * f.T;

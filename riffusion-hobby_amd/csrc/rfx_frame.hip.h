@@ -39,6 +39,16 @@ template <int AUX = 0>
 __device__ __forceinline__ v2f ld2(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
 }
+// integer tables.  NOT `bit_cast<unsigned>(ld2(...).y)`: hipcc (ROCm 7.2) narrows a 64-bit buffer load whose float halves are both
+// bit-cast back to integers to a 32-bit load and hands out the low half twice (seen in the IR and the ISA, round 5).
+template <int AUX = 0>
+__device__ __forceinline__ unsigned ld1u(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ v2u ld2u(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+}
 template <int AUX = 0>
 __device__ __forceinline__ v4f ld4(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
@@ -160,12 +170,21 @@ struct Tw2Stage {
 struct Tw1 {
   cf w[21];
 };
+// SHORT (round 5, forward kernel): only g^1 .. g^10 and g^20 are fetched (g^20 parked in w[11]); tw1_get derives the rows
+// 11..19 at the point of use as g^(20-k) = g^20 conj(g^k), like rfx_fam_core.h::fam_g_pow: 88 instead of 160 bytes per thread
+// and frame from L2 and 18 registers less in flight, for nine more packed complex products in P1
+template <bool SHORT = false>
 __device__ __forceinline__ void load_tw1(Tw1& tw, const FrameCtx& f) {
 #pragma unroll
-  for (int k = 1; k < 21; ++k) {
-    v2f w = ld2(f.tw1, f.npr8, (unsigned)k * (kHop * 8u));
+  for (int k = 1; k < (SHORT ? 12 : 21); ++k) {
+    v2f w = ld2(f.tw1, f.npr8, (unsigned)(SHORT && k == 11 ? 20 : k) * (kHop * 8u));
     tw.w[k] = cf{w.x, w.y};
   }
+}
+template <bool SHORT>
+__device__ __forceinline__ cf tw1_get(const Tw1& tw, int k) {
+  if (!SHORT || k <= 10) return tw.w[k];
+  return k == 20 ? tw.w[11] : cmulc(tw.w[11], tw.w[20 - k]);
 }
 
 // forward transform of one frame: u[10] (windowed samples of thread n') -> R[21] (slots of thread q).
@@ -175,11 +194,11 @@ struct NoHook {
   __device__ __forceinline__ void operator()() const {}
   __device__ __forceinline__ void operator()(int) const {}
 };
-template <class Hook, class Pre = NoHook, class Mid = NoHook>
+template <bool TWSHORT = false, class Hook, class Pre = NoHook, class Mid = NoHook>
 __device__ __forceinline__ void frame_forward_tw(const float (&u)[10], cf (&R)[21], const FrameCtx& f, const ThreadId& t,
                                                  const Tw1& tw, Hook after_barrier, Pre before_barrier = Pre(),
                                                  Mid before_p3 = Mid()) {
-  if (t.active) p1_forward_store(u, [&tw](int k) { return tw.w[k]; }, f.cube, t.npr);
+  if (t.active) p1_forward_store(u, [&tw](int k) { return tw1_get<TWSHORT>(tw, k); }, f.cube, t.npr);
   before_barrier();
   __syncthreads();
 #ifndef RFX_NO_PRIO

@@ -108,10 +108,24 @@ struct StftMelArgs {
   const int* slot_at;    // [21][kQPad] LDS position of the slot's w0 product (the lane's dump position for a slot that contributes nothing)
   const int* pad_tab;    // [kMelPadsPerThread][kQPad] LDS positions of the zero padding this thread rewrites every frame (dump if none)
   const int* filt_seg;   // [2][Mpad]: rising segment, falling segment, each as (first float << 4) | number of 16-byte reads
-  int prod_arr;          // floats between the w0 and the w1 product arrays
+  int prod_arr;          // floats between the w0 and the w1 product arrays (and between their dump floats)
   unsigned kb_mask;      // bit kb set when any thread's slot kb contributes
+  // the same tables in the packed form the default-bank kernel reads (round 5; null when the bank needs kb outside kKbMaskLow or
+  // more than kMelProdArr floats per array): LDS BYTE addresses as 16-bit halves, prod_arr == kMelProdArr
+  const unsigned* pk_at;   // [5][kQPad]: word i = byte address of the w0 product of the thread's contributing slots 2 i (low half) and 2 i + 1 (high half), slots in increasing kb
+  const unsigned* pk_pad;  // [kQPad][2]: the thread's kMelPadsPerThread zero-padding byte addresses, two per word
+  const unsigned* pk_seg;  // [Mpad][2]: {rising, falling} segment of filter m, each (first float << 4) | number of 16-byte reads
+  // image_util.image_from_spectrogram's maximum (image_util.py:41) taken on the fly (rfx_image_from_waveform): when not null,
+  // max_keys[clip / max_group] receives an atomicMax of the order-preserving key (rfx_codec.hip::max_key) of every mel
+  // amplitude the launch forms; the launcher then leaves out the transpose to (B, M, T)
+  unsigned* max_keys;
+  int max_group;           // channels per image (1 mono, 2 stereo)
 };
 constexpr int kMelPadsPerThread = 4;
+// the kb (of a thread's 21 slots) that can contribute, as a compile-time set: 0x1F001F (kb 0..4 and 16..20) covers every bank that
+// ends at or below bin 4200 (the default 0-10 kHz bank: bins 1..4000), 0x1FFFFF any bank
+constexpr unsigned kKbMaskLow = 0x1F001Fu, kKbMaskAll = 0x1FFFFFu;
+constexpr int kMelProdArr = 8192;  // floats between the w0 and the w1 product arrays whenever the first one ends below it (a compile-time LDS offset for the packed form)
 hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream);
 
 // mel projection GEMM: out[b][m][t] = sum_p fbs[p][m] * mag[b*T+t][p]
@@ -298,6 +312,10 @@ hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out,
 hipError_t launch_clip_max(const float* x, float* out, int nclips, size_t count, bool abs_value, hipStream_t s);
 hipError_t launch_image_encode(const float* mel, const float* clip_max, const float* thr, uint8_t* img, int N, int M, int T,
                                int C, hipStream_t s);
+// encode straight from the forward kernels' frame-major mel amplitudes [N*C][T][Mpad] (rfx_image_from_waveform): the transpose to the
+// image's (mel, time) order happens in LDS; the maximum comes as a key (max_keys, from the forward kernel) or as a float (clip_max)
+hipError_t launch_image_encode_tm(const float* mel_tm, const unsigned* max_keys, const float* clip_max_in, const float* thr, uint8_t* img,
+                                  float* clip_max_out, int N, int M, int Mpad, int T, int C, hipStream_t s);
 hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s);
 
 }  // namespace rfx

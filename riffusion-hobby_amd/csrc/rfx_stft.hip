@@ -262,15 +262,33 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) { 
 //    loads per frame and workgroup).
 // Cost: two more workgroup barriers per frame (all waves must have left P3 before the cube is overwritten with products).
 // Measured (B = 64, T = 512): 0.83 -> 0.69 ms; ablations: transform alone 0.46 ms, + product exchange 0.58 ms.
-// KBMASK: the kb (of a thread's 21 slots) that can contribute, as a compile-time set: 0x1F001F (kb 0..4 and 16..20) covers
-// every bank that ends at or below bin 4200 (the default 0-10 kHz bank: bins 1..4000), 0x1FFFFF any bank.
-constexpr unsigned kKbMaskLow = 0x1F001Fu, kKbMaskAll = 0x1FFFFFu;
-template <unsigned KBMASK>
+// KBMASK: the kb (of a thread's 21 slots) that can contribute, as a compile-time set (rfx_kernels.h: kKbMaskLow / kKbMaskAll).
+// Round 5: what the mel half costs is its TABLE TRAFFIC, not the exchange (profiles/r05_forward_ablation.txt): every frame each
+// thread re-fetches 392 B of frame-invariant constants from L2 (no registers to keep them: 128 VGPRs), 152 B of them for the mel
+// phase; without the mel tables the kernel takes 0.45 ms, with them and no exchange / no sums 0.535, complete 0.58.  PK (the
+// default-bank form, KBMASK == kKbMaskLow and a plan that holds the packed tables): product positions and padding positions as
+// 16-bit LDS byte addresses (two per dword), both segments of a filter in one 8-byte load, the second array at a compile-time
+// offset (one address register serves both stores), the second filter's segments fetched by the first wave only; and for
+// every form the g(n')^k1 twiddles of the rows 11..19 are derived from those of the rows 1..10 and 20 (g^(20-k) = g^20 conj(g^k),
+// as the row-family kernels do: nine packed complex products instead of 72 B per thread and frame).
+#ifndef RFX_FWD_ABL
+#define RFX_FWD_ABL 0  // timing ablations of -DRFX_ABLATION builds (wrong results): 2 no product scatter, 3 no segment sums,
+#endif                 // 4 transform + table fetches only, 5 no mel tables either
+#ifndef RFX_FWD_OPT
+#define RFX_FWD_OPT 31  // bit 0: packed mel tables (PK), bit 1: short twiddle table, bits 2-4 below
+#endif
+constexpr bool kFwdTwShort = (RFX_FWD_OPT & 2) != 0;
+constexpr bool kFwdWinRegs = (RFX_FWD_OPT & 4) != 0;  // the ten Hann samples stay in registers over the run
+constexpr bool kFwdSlide = (RFX_FWD_OPT & 8) != 0;    // sliding input window: one new sample per frame
+constexpr bool kFwdIdxRegs = (RFX_FWD_OPT & 16) != 0; // PK: the packed positions / padding / segments stay in registers over the run
+template <unsigned KBMASK, bool PK>
 __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ThreadId t = thread_id();
   const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
-  float* prod = reinterpret_cast<float*>(smem);  // [0, arr): w0 * |X|, group-padded; [arr, 2 arr): w1 * |X|; then one dump float per lane
+  float* prod = reinterpret_cast<float*>(smem);  // [0, kQPad): one dump float per lane, then w0 * |X|, group-padded; the same for w1 * |X| from prod_arr on
+  constexpr int NKB = __builtin_popcount(KBMASK);
+  static_assert(!PK || (KBMASK == kKbMaskLow && NKB == 10), "the packed tables hold ten slots per thread");
 
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   const int clip = blockIdx.x / chunks;
@@ -279,15 +297,16 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   const rsrc_t xin = make_rsrc(a.wave + (size_t)clip * a.Lw, (size_t)a.Lw * 4);
   const rsrc_t win = make_rsrc(a.win, kWin * 4);
   const rsrc_t slots = make_rsrc(a.slot_tab, 21 * kQPad * 8);
-  const rsrc_t slotat = make_rsrc(a.slot_at, 21 * kQPad * 4);
   // Frame-invariant per-thread constants that are only needed in the short mel phase (where the products go, the segments
   // of the thread's filters, its share of the zero padding) are re-fetched from their L2-resident tables every frame, in
   // flight across the barrier that precedes their use: held in registers they are spilled around the transform and reloaded
   // on the spot (seen in the ISA).
-  const rsrc_t segsrc = make_rsrc(a.filt_seg, (size_t)2 * a.Mpad * 4);
-  const rsrc_t padsrc = make_rsrc(a.pad_tab, (size_t)kMelPadsPerThread * kQPad * 4);
+  const rsrc_t slotat = PK ? make_rsrc(a.pk_at, 5 * kQPad * 4) : make_rsrc(a.slot_at, 21 * kQPad * 4);
+  const rsrc_t segsrc = PK ? make_rsrc(a.pk_seg, (size_t)2 * a.Mpad * 4) : make_rsrc(a.filt_seg, (size_t)2 * a.Mpad * 4);
+  const rsrc_t padsrc = PK ? make_rsrc(a.pk_pad, 2 * kQPad * 4) : make_rsrc(a.pad_tab, (size_t)kMelPadsPerThread * kQPad * 4);
   const unsigned npr4 = (unsigned)t.npr * 4u;
   const unsigned qp4 = (unsigned)slot_qp(t.npr) * 4u;
+  const bool second = kThreads < a.Mpad && threadIdx.x < 64;  // wave-uniform: the first wave carries the filters past kThreads
 
   // the thread's ten Hann samples: like the twiddles, fetched during the mel phase of the previous frame
   float w10[10];
@@ -305,9 +324,39 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
 #pragma unroll
     for (int j = 0; j < 10; ++j) d[j] = load_x(fr + j - kHalfHops);
   };
+  auto next_frame = [&](int fr) {  // the samples of frame fr, given those of frame fr - 1
+    if (kFwdSlide) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) d[j] = d[j + 1];
+      d[9] = load_x(fr + 9 - kHalfHops);
+    } else {
+      load_frame(fr);
+    }
+  };
   load_frame(f0);
   Tw1 tw1;
-  load_tw1(tw1, f);
+  load_tw1<kFwdTwShort>(tw1, f);
+  // where the products go, this thread's zero-padding positions, and the segments of its (up to two) filters - threadIdx
+  // and threadIdx + kThreads (the first wave carries the second filters: they are the LONGEST bands, its first filters
+  // the shortest).  Plain form: float positions, one per dword; PK: byte addresses, two per dword (sat[i] = slots 2 i and
+  // 2 i + 1 of the thread's ten).
+  unsigned sat[PK ? 5 : 21], pad_at[PK ? 2 : kMelPadsPerThread], seg[2][2] = {{0u, 0u}, {0u, 0u}};
+  auto load_pk_tables = [&] {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sat[i] = ld1u(slotat, qp4, (unsigned)i * (kQPad * 4u));
+    const v2u pp = ld2u(padsrc, 2u * qp4, 0);
+    pad_at[0] = pp.x;
+    pad_at[1] = pp.y;
+    const v2u s0 = ld2u(segsrc, threadIdx.x * 8u, 0);
+    seg[0][0] = s0.x;
+    seg[0][1] = s0.y;
+    if (second) {
+      const v2u s1 = ld2u(segsrc, (threadIdx.x + kThreads) * 8u, 0);
+      seg[1][0] = s1.x;
+      seg[1][1] = s1.y;
+    }
+  };
+  if constexpr (PK && kFwdIdxRegs) load_pk_tables();
   __syncthreads();  // tw2 table in LDS
 
   for (int fr = f0; fr < f1; ++fr) {
@@ -316,13 +365,16 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
     for (int j = 0; j < 10; ++j) u[j] = d[j] * w10[j];
     cf R[21];
     float sw0[21], sw1[21];  // per contributing slot: weights of its bin on its first / second filter, then their products with |X|
-    frame_forward_tw(u, R, f, t, tw1,
+    frame_forward_tw<kFwdTwShort>(u, R, f, t, tw1,
                      NoHook(),
                      NoHook(),
                      [&] {  // before P3 (P2's registers are free): the slots' weights fly under P3
 #pragma unroll
                        for (int kb = 0; kb < 21; ++kb)
-                         if ((KBMASK >> kb) & 1u) {
+                         if (RFX_FWD_ABL >= 5) {
+                           sw0[kb] = 1.f;
+                           sw1[kb] = 2.f;
+                         } else if ((KBMASK >> kb) & 1u) {
                            const v2f e = ld2(slots, 2u * qp4, (unsigned)kb * (kQPad * 8u));
                            sw0[kb] = e.x;
                            sw1[kb] = e.y;
@@ -336,40 +388,99 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
         sw0[kb] *= mag;
         sw1[kb] *= mag;
       }
-    // where the products go, this thread's zero-padding positions, and the segments of its (up to two) filters - threadIdx
-    // and threadIdx + kThreads (the first wave carries the second filters: they are the LONGEST bands, its first filters
-    // the shortest): needed right behind the next two barriers, in flight across them
-    int sat[21], pad_at[kMelPadsPerThread], seg[2][2];
+    // the mel phase's positions: needed right behind the next two barriers, in flight across them
+    if constexpr (!(PK && kFwdIdxRegs)) {
+#if RFX_FWD_ABL >= 5
 #pragma unroll
-    for (int kb = 0; kb < 21; ++kb)
-      if ((KBMASK >> kb) & 1u) sat[kb] = __builtin_bit_cast(int, ld1(slotat, qp4, (unsigned)kb * (kQPad * 4u)));
+    for (int i = 0; i < (PK ? 5 : 21); ++i) sat[i] = 0;
 #pragma unroll
-    for (int i = 0; i < kMelPadsPerThread; ++i) pad_at[i] = __builtin_bit_cast(int, ld1(padsrc, qp4, (unsigned)i * (kQPad * 4u)));
+    for (int i = 0; i < (PK ? 2 : kMelPadsPerThread); ++i) pad_at[i] = 0;
+#else
+    if constexpr (PK) {
+      load_pk_tables();
+    } else {
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
+      for (int kb = 0; kb < 21; ++kb)
+        if ((KBMASK >> kb) & 1u) sat[kb] = ld1u(slotat, qp4, (unsigned)kb * (kQPad * 4u));
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        seg[w][h] = __builtin_bit_cast(int, ld1(segsrc, (threadIdx.x + w * kThreads) * 4u, (unsigned)h * (unsigned)a.Mpad * 4u));
+      for (int i = 0; i < kMelPadsPerThread; ++i) pad_at[i] = ld1u(padsrc, qp4, (unsigned)i * (kQPad * 4u));
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          seg[w][h] = ld1u(segsrc, (threadIdx.x + w * kThreads) * 4u, (unsigned)h * (unsigned)a.Mpad * 4u);
+    }
+#endif
+    }
+#if RFX_FWD_ABL >= 4  // ablation: the transform and the table fetches only (no exchange, no sums; one barrier before the next P1)
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 21; ++kb)
+        if ((KBMASK >> kb) & 1u) s += sw0[kb] + sw1[kb];
+#pragma unroll
+      for (int i = 0; i < (PK ? 5 : 21); ++i)
+        if (PK || ((KBMASK >> i) & 1u)) s += __builtin_bit_cast(float, sat[i]);
+#pragma unroll
+      for (int i = 0; i < (PK ? 2 : kMelPadsPerThread); ++i) s += __builtin_bit_cast(float, pad_at[i]);
+      s += __builtin_bit_cast(float, seg[0][0] + seg[0][1] + seg[1][0] + seg[1][1]);
+      load_tw1<kFwdTwShort>(tw1, f);
+      if (!kFwdWinRegs) load_window();
+      next_frame(fr + 1);
+      if (threadIdx.x < a.Mpad) a.mel_tm[((size_t)clip * a.T + fr) * a.Mpad + threadIdx.x] = s;
+      __syncthreads();
+      continue;
+    }
+#endif
     __syncthreads();  // every wave has left P3: the cube may be overwritten
 #ifndef RFX_NO_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    if (t.active) {  // slots that contribute nothing (duplicates, bins outside the bank) carry zero weights and the lane's dump position
+    if (t.active && RFX_FWD_ABL != 2) {  // slots that contribute nothing (duplicates, bins outside the bank) carry zero weights and the lane's dump position
+      if constexpr (PK) {
+        auto put = [&](unsigned byte_at, float p0, float p1) {
+          float* at = reinterpret_cast<float*>(smem + byte_at);
+          at[0] = p0;
+          at[kMelProdArr] = p1;
+        };
+        int n = 0;
 #pragma unroll
-      for (int kb = 0; kb < 21; ++kb)
-        if ((KBMASK >> kb) & 1u) {
-          prod[sat[kb]] = sw0[kb];
-          prod[sat[kb] + a.prod_arr] = sw1[kb];
+        for (int kb = 0; kb < 21; ++kb)
+          if ((KBMASK >> kb) & 1u) {
+            put((n & 1) ? sat[n >> 1] >> 16 : sat[n >> 1] & 0xffffu, sw0[kb], sw1[kb]);
+            ++n;
+          }
+#pragma unroll
+        for (int i = 0; i < kMelPadsPerThread; ++i) put((i & 1) ? pad_at[i >> 1] >> 16 : pad_at[i >> 1] & 0xffffu, 0.f, 0.f);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 21; ++kb)
+          if ((KBMASK >> kb) & 1u) {
+            prod[sat[kb]] = sw0[kb];
+            prod[sat[kb] + a.prod_arr] = sw1[kb];
+          }
+#pragma unroll
+        for (int i = 0; i < kMelPadsPerThread; ++i) {
+          prod[pad_at[i]] = 0.f;
+          prod[pad_at[i] + a.prod_arr] = 0.f;
         }
-#pragma unroll
-      for (int i = 0; i < kMelPadsPerThread; ++i) {
-        prod[pad_at[i]] = 0.f;
-        prod[pad_at[i] + a.prod_arr] = 0.f;
       }
     }
-    load_tw1(tw1, f);  // for the next frame's P1: in flight across the mel phase
-    load_window();
-    load_frame(fr + 1);
+#if RFX_FWD_ABL == 2
+    if (t.active) {  // (the registers stay alive through one dump store)
+      float s = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 21; ++kb)
+        if ((KBMASK >> kb) & 1u) s += sw0[kb] + sw1[kb];
+#pragma unroll
+      for (int i = 0; i < (PK ? 5 : 21); ++i)
+        if (PK || ((KBMASK >> i) & 1u)) s += __builtin_bit_cast(float, sat[i]);
+      prod[threadIdx.x & 63] = s;
+    }
+#endif
+    load_tw1<kFwdTwShort>(tw1, f);  // for the next frame's P1: in flight across the mel phase
+    if (!kFwdWinRegs) load_window();
+    next_frame(fr + 1);
     __syncthreads();
     {
       // Results go to a frame-major scratch (Mpad contiguous floats per frame: whole-line stores); a tiled transpose brings
@@ -392,7 +503,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
       // One filter: the first 16 products of its rising AND of its falling segment are requested together (one LDS round
       // trip; every lane issues them all: a lane whose segment is shorter reads into its neighbours' products or the dump
       // area - always inside the cube - and does not add them), then the sums: rising part first, in bin order.
-      auto filter_sum = [&](int sr, int sf) {
+      auto filter_sum = [&](unsigned sr, unsigned sf) {
         const v4f* pa = prod4 + (sr >> 6);  // segments start on 16-byte boundaries
         const v4f* pb = prod4 + (sf >> 6);
         const int na = sr & 15, nb4 = sf & 15;
@@ -412,12 +523,18 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
           if (j < nb4) s = add4(s, rb[j]);
         return tail(s, pb, nb4);
       };
+#if RFX_FWD_ABL == 3  // ablation: no segment sums (one LDS read per thread keeps the exchange alive)
+      const float s0 = prod[seg[0][0] >> 4] + prod[seg[0][1] >> 4];
+      if (threadIdx.x < a.Mpad) row[threadIdx.x] = s0;
+      if (second && threadIdx.x + kThreads < a.Mpad) row[threadIdx.x + kThreads] = prod[seg[1][0] >> 4] + prod[seg[1][1] >> 4];
+#else
       const float s0 = filter_sum(seg[0][0], seg[0][1]);
       if (threadIdx.x < a.Mpad) row[threadIdx.x] = s0;  // padding filters (m >= M): empty segments, 0
-      if (kThreads < a.Mpad && threadIdx.x < 64) {      // wave-uniform: the first wave carries the filters past kThreads
+      if (second) {
         const float s1 = filter_sum(seg[1][0], seg[1][1]);
         if (threadIdx.x + kThreads < a.Mpad) row[threadIdx.x + kThreads] = s1;
       }
+#endif
     }
     __syncthreads();  // the next frame's P1 overwrites the products
   }
@@ -446,24 +563,25 @@ hipError_t launch_mel_transpose(const float* mel_tm, float* mel, int B, int T, i
 
 hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream) {
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
-  if (a.slot_tab && (a.kb_mask & ~kKbMaskLow) == 0)
-    hipLaunchKernelGGL(stft_mel2_kernel<kKbMaskLow>, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
+  const dim3 grid(a.B * chunks), block(kThreads);
+  if (a.slot_tab && (a.kb_mask & ~kKbMaskLow) == 0 && a.pk_at && (RFX_FWD_OPT & 1))
+    hipLaunchKernelGGL((stft_mel2_kernel<kKbMaskLow, true>), grid, block, kFrameDynLdsBytes, stream, a);
+  else if (a.slot_tab && (a.kb_mask & ~kKbMaskLow) == 0)
+    hipLaunchKernelGGL((stft_mel2_kernel<kKbMaskLow, false>), grid, block, kFrameDynLdsBytes, stream, a);
   else if (a.slot_tab)
-    hipLaunchKernelGGL(stft_mel2_kernel<kKbMaskAll>, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
-  else hipLaunchKernelGGL(stft_mel_kernel, dim3(a.B * chunks), dim3(kThreads), kFrameDynLdsBytes, stream, a);
+    hipLaunchKernelGGL((stft_mel2_kernel<kKbMaskAll, false>), grid, block, kFrameDynLdsBytes, stream, a);
+  else hipLaunchKernelGGL(stft_mel_kernel, grid, block, kFrameDynLdsBytes, stream, a);
   const hipError_t e = hipGetLastError();
   return e != hipSuccess ? e : launch_mel_transpose(a.mel_tm, a.mel, a.B, a.T, a.M, a.Mpad, stream);
 }
 
 hipError_t prepare_frame_kernels() {
-  hipError_t e = hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)stft_mel2_kernel<kKbMaskLow>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)stft_mel2_kernel<kKbMaskAll>, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
-  return e != hipSuccess ? e : prepare_gl_kernels();
+  for (const void* fn : {(const void*)stft_kernel, (const void*)stft_mel_kernel, (const void*)stft_mel2_kernel<kKbMaskLow, true>,
+                         (const void*)stft_mel2_kernel<kKbMaskLow, false>, (const void*)stft_mel2_kernel<kKbMaskAll, false>}) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kFrameDynLdsBytes);
+    if (e != hipSuccess) return e;
+  }
+  return prepare_gl_kernels();
 }
 
 hipError_t launch_stft(const StftArgs& a, hipStream_t stream) {

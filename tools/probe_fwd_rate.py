@@ -23,10 +23,14 @@ for rate in [int(r) for r in os.environ.get("RATES", "48000").split(",")]:
     for _ in range(10): step()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
+    e0.record()
+    for _ in range(20): plan.mel_from_waveform(wave)
+    e1.record(); torch.cuda.synchronize()
+    ms_mel = e0.elapsed_time(e1) / 20
     # spot check of clip 0 against torch.stft on the device (the reference's definition, dense filterbank)
     win = torch.hann_window(p.win_length, device="cuda")
     ref = torch.stft(wave[:1], p.n_fft, p.hop_length, p.win_length, win, center=True, pad_mode="reflect", return_complex=True).abs()
     ref_mel = (ref.transpose(1, 2) @ plan.melfb.cuda()).transpose(1, 2)
     rel = float(torch.linalg.norm(mel[:1] - ref_mel) / torch.linalg.norm(ref_mel))
-    out.append(f"{rate}: {ms:.3f} ms per {B} clips = {B / ms * 1e3:.0f} images/s [{plan.griffinlim_engine}] rel-L2 vs torch.stft {rel:.1e}")
+    out.append(f"{rate}: {ms:.3f} ms per {B} clips (mel alone {ms_mel:.3f}) = {B / ms * 1e3:.0f} images/s [{plan.griffinlim_engine}] rel-L2 vs torch.stft {rel:.1e}")
 print(os.environ.get("TAG", "default") + "  " + " | ".join(out), flush=True)
