@@ -181,6 +181,16 @@ size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw);
 int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
                           size_t workspace_bytes, void* stream);
 
+/* ---- forward, all the way to the image: SpectrogramImageConverter.spectrogram_image_from_audio's device half
+ * (spectrogram_image_converter.py:30-51: spectrogram_from_audio, then image_util.image_from_spectrogram, image_util.py:27-54).
+ * d_wave (N*C, Lw) float32 (C = 2 when stereo: the channels of clip n are rows 2n, 2n+1) -> d_img_out (N, n_mels, T, 3) uint8 and
+ * d_clip_max (N floats: the EXIF MAX_VALUE, spectrogram_image_converter.py:45-49).  Byte-identical to rfx_mel_from_waveform
+ * followed by rfx_image_encode_u8; the (N*C, n_mels, T) tensor is never written: the maximum is taken while the mel amplitudes
+ * are formed and the encoder reads the forward kernel's frame-major scratch. */
+size_t rfx_image_from_waveform_workspace_bytes(const rfx_plan* plan, int N, int stereo, int Lw);
+int rfx_image_from_waveform(const rfx_plan* plan, const float* d_wave, int N, int stereo, int Lw, const float* d_thresholds255,
+                            float* d_clip_max, uint8_t* d_img_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Standalone torchaudio.transforms.MelScale.forward (spectrogram_converter.py:185) for callers that hold linear
  * magnitudes in the reference's (B, n_stft, T) layout: packs them into slots and runs the same MFMA projection.
  * Workspace: rfx_mel_scale_workspace_bytes. */

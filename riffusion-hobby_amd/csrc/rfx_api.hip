@@ -1266,9 +1266,15 @@ size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw) {
   return align_up((size_t)B * T * kFrameStride * sizeof(float), 256);
 }
 
-int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
-                          size_t workspace_bytes, void* stream) {
-  if (!plan || !d_wave || !d_mel_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: null argument");
+// does the plan's forward path leave the mel amplitudes frame-major ([B*T][Mpad]) in the workspace before transposing them?
+static bool forward_has_frame_major(const rfx_plan* plan) { return plan->generic ? plan->fwd_ok : (plan->fwd_ok && !plan->fwd_unfused); }
+
+// rfx_mel_from_waveform, and the front half of rfx_image_from_waveform: there d_mel_out is null (no (B, M, T) copy is made),
+// *mel_tm_out receives the frame-major amplitudes and - where the kernel can take it on the fly - max_keys[clip / max_group] the
+// key of the maximum (*keys_done says whether it did)
+static int mel_forward(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace, size_t workspace_bytes,
+                       void* stream, float** mel_tm_out, unsigned* max_keys, int max_group, bool* keys_done) {
+  if (!plan || !d_wave || !d_workspace || (!d_mel_out && !mel_tm_out)) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: null argument");
   if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: plan was created without a mel filterbank");
   if (workspace_bytes < rfx_mel_workspace_bytes(plan, B, Lw) || Lw <= plan->p.n_fft / 2)
     return fail(Lw <= plan->p.n_fft / 2 ? RFX_ERR_INVALID : RFX_ERR_WORKSPACE, "rfx_mel_from_waveform: input too short or workspace too small");
@@ -1299,14 +1305,16 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
       fa.Mpad = plan->Mpad;
       const long long nframes = (long long)B * T, slots = (long long)plan->num_cus * plan->fam_wgs_per_cu;
       RFX_HIP(launch_fam_fwd(2, fa, (int)(nframes < slots ? nframes : slots), (hipStream_t)stream));
-      RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+      if (mel_tm_out) *mel_tm_out = mel_tm;
+      if (d_mel_out) RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
       return RFX_OK;
     }
     int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
     if (rc) return rc;
     RFX_HIP(launch_gen_mel(mag, mel_tm, plan->d_band_wt, plan->d_band_lo, plan->d_band_lo + plan->Mpad, (long long)B * T, plan->gg.fs,
                            plan->p.n_mels, plan->Mpad, plan->imel.f_lo, plan->imel.f_hi, (hipStream_t)stream));
-    RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
+    if (mel_tm_out) *mel_tm_out = mel_tm;
+    if (d_mel_out) RFX_HIP(launch_mel_transpose(mel_tm, d_mel_out, B, T, plan->p.n_mels, plan->Mpad, (hipStream_t)stream));
     return RFX_OK;
   }
   if (plan->fwd_ok && !plan->fwd_unfused) {
@@ -1337,6 +1345,10 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     f.pk_at = plan->fwd_packed_off ? reinterpret_cast<const unsigned*>(plan->d_slot_idx + plan->fwd_packed_off) : nullptr;
     f.pk_pad = f.pk_at ? f.pk_at + 5 * (size_t)kQPad : nullptr;
     f.pk_seg = f.pk_at ? f.pk_pad + 2 * (size_t)kQPad : nullptr;
+    f.max_keys = plan->d_slot_tab ? max_keys : nullptr;  // (the product-form kernel takes the maximum on the fly)
+    f.max_group = max_group > 0 ? max_group : 1;
+    if (keys_done) *keys_done = f.max_keys != nullptr;
+    if (mel_tm_out) *mel_tm_out = f.mel_tm;
     // runs of consecutive frames: every resident workgroup slot of the chip gets one run when the batch allows it (the
     // product-form kernel carries a sliding input window along a run), at most 64 frames, at least 1
     const long long frames = (long long)B * f.T;
@@ -1346,6 +1358,7 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
     RFX_HIP(launch_stft_mel(f, (hipStream_t)stream));
     return RFX_OK;
   }
+  if (!d_mel_out) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: this plan's forward path has no frame-major stage");
   float* mag = (float*)d_workspace;
   int rc = rfx_stft(plan, d_wave, B, Lw, mag, nullptr, stream);
   if (rc) return rc;
@@ -1360,6 +1373,52 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
   a.T = 1 + Lw / kHop;
   a.N = B * a.T;
   RFX_HIP(launch_mel_gemm(a, (hipStream_t)stream));
+  return RFX_OK;
+}
+
+int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!d_mel_out) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: null argument");
+  return mel_forward(plan, d_wave, B, Lw, d_mel_out, d_workspace, workspace_bytes, stream, nullptr, nullptr, 1, nullptr);
+}
+
+// ---- spectrogram_image_from_audio's device half (spectrogram_image_converter.py:30-51: spectrogram_from_audio, then
+// image_util.image_from_spectrogram): waveforms -> mel amplitudes -> uint8 image without the (B, M, T) tensor in between
+size_t rfx_image_from_waveform_workspace_bytes(const rfx_plan* plan, int N, int stereo, int Lw) {
+  if (!plan || N <= 0) return 0;
+  const int C = stereo ? 2 : 1;
+  const size_t mel_ws = rfx_mel_workspace_bytes(plan, N * C, Lw);
+  if (!mel_ws) return 0;
+  size_t total = mel_ws + align_up((size_t)N * sizeof(unsigned), 256);
+  if (!forward_has_frame_major(plan)) total += align_up((size_t)N * C * plan->p.n_mels * stft_frames(plan, Lw) * sizeof(float), 256);
+  return total;
+}
+
+int rfx_image_from_waveform(const rfx_plan* plan, const float* d_wave, int N, int stereo, int Lw, const float* d_thresholds255,
+                            float* d_clip_max, uint8_t* d_img_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!plan || !d_wave || !d_thresholds255 || !d_clip_max || !d_img_out || !d_workspace || N <= 0)
+    return fail(RFX_ERR_INVALID, "rfx_image_from_waveform: bad argument");
+  if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_image_from_waveform: plan was created without a mel filterbank");
+  if (Lw <= plan->p.n_fft / 2) return fail(RFX_ERR_INVALID, "rfx_image_from_waveform: input too short");
+  if (workspace_bytes < rfx_image_from_waveform_workspace_bytes(plan, N, stereo, Lw)) return fail(RFX_ERR_WORKSPACE, "rfx_image_from_waveform: workspace too small");
+  RFX_ON_DEVICE(plan->device);
+  const int C = stereo ? 2 : 1, B = N * C, T = stft_frames(plan, Lw), M = plan->p.n_mels;
+  const size_t mel_ws = rfx_mel_workspace_bytes(plan, B, Lw);
+  unsigned* keys = reinterpret_cast<unsigned*>((char*)d_workspace + mel_ws);
+  if (!forward_has_frame_major(plan)) {  // (dense-GEMM fall-back of a non-banded bank: the two calls, the tensor in the workspace)
+    float* mel = reinterpret_cast<float*>((char*)keys + align_up((size_t)N * sizeof(unsigned), 256));
+    if (int rc = rfx_mel_from_waveform(plan, d_wave, B, Lw, mel, d_workspace, mel_ws, stream)) return rc;
+    return rfx_image_encode_u8(mel, N, M, T, stereo, d_thresholds255, d_clip_max, d_img_out, stream);
+  }
+  RFX_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned) * (size_t)N, (hipStream_t)stream));
+  float* mel_tm = nullptr;
+  bool keys_done = false;
+  if (int rc = mel_forward(plan, d_wave, B, Lw, nullptr, d_workspace, mel_ws, stream, &mel_tm, keys, C, &keys_done)) return rc;
+  // (a kernel that does not take the maximum on the fly: one pass over the frame-major amplitudes; their padding columns are zero
+  // and mel amplitudes are not negative)
+  if (!keys_done) RFX_HIP(launch_clip_max(mel_tm, reinterpret_cast<float*>(keys), N, (size_t)C * T * plan->Mpad, false, (hipStream_t)stream));
+  RFX_HIP(launch_image_encode_tm(mel_tm, keys_done ? keys : nullptr, keys_done ? nullptr : reinterpret_cast<const float*>(keys), d_thresholds255,
+                                 d_img_out, d_clip_max, N, M, plan->Mpad, T, C, (hipStream_t)stream));
   return RFX_OK;
 }
 

@@ -42,13 +42,7 @@ __global__ void __launch_bounds__(256) image_decode_kernel(const uint8_t* __rest
 // workgroups (float4 loads); partial maxima meet in an atomicMax on an order-preserving integer key
 // (positive NaN is the largest key, so np.max's NaN propagation comes for free), a last tiny kernel
 // turns the keys back into floats in place.
-__device__ __forceinline__ unsigned max_key(float v) {
-  unsigned b = __float_as_uint(v);
-  if (v != v) b = 0x7FC00000u;
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float key_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
-
+// (max_key / key_value: rfx_kernels.h)
 template <bool ABS>
 __global__ void __launch_bounds__(256) clip_max_kernel(const float* __restrict__ x, unsigned* __restrict__ keys, size_t count, int splits) {
   __shared__ unsigned red[4];
@@ -136,6 +130,81 @@ __global__ void __launch_bounds__(128) image_encode_kernel(const float* __restri
   }
 }
 
+// ---- encode from the forward kernels' frame-major scratch (rfx_image_from_waveform; round 5): mel_tm [N*C][T][Mpad] -> img
+// (N, M, T, 3).  What rfx_image_encode_u8 does after a transpose to (N*C, M, T), without the transposed copy (134 MB written and
+// read back per 64 tiles) and without a pass for the maximum (the forward kernel hands it over as a key).  A workgroup takes a tile
+// of 128 frames x 32 mel bins per channel: whole 128-byte lines in (32 floats of a frame), transposed in LDS, and out as 384
+// contiguous bytes per image row (twelve bytes per thread, whole lines).  Same quantiser as image_encode_kernel, bit for bit.
+constexpr int kEncTmT = 128, kEncTmM = 32, kEncTmPitch = kEncTmT + 4;  // LDS row = one mel bin's 128 frames (+4: 16-byte reads stay aligned, rows shift banks)
+__global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __restrict__ mel_tm, const unsigned* __restrict__ max_keys,
+                                                             const float* __restrict__ clip_max_in, const float* __restrict__ thr,
+                                                             uint8_t* __restrict__ img, float* __restrict__ clip_max_out, int M,
+                                                             int Mpad, int T, int C) {
+  __shared__ float thr_s[256];
+  __shared__ __attribute__((aligned(16))) float tile[2][kEncTmM][kEncTmPitch];
+  thr_s[threadIdx.x] = threadIdx.x < 255 ? thr[threadIdx.x] : -__builtin_inff();
+  const int t0 = blockIdx.x * kEncTmT, m0 = blockIdx.y * kEncTmM;
+  const size_t n = blockIdx.z;
+  const float mx = max_keys ? key_value(max_keys[n]) : clip_max_in[n];
+  if (clip_max_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clip_max_out[n] = mx;
+  // in: thread (frame r of 32, quad of four mel bins): four passes over the tile's 128 frames
+  {
+    const int mq = 4 * (threadIdx.x & 7), r0 = threadIdx.x >> 3;
+    for (int c = 0; c < C; ++c) {
+      const float* __restrict__ src = mel_tm + ((n * C + c) * (size_t)T) * Mpad + m0 + mq;  // (m0 + mq + 3 < Mpad: Mpad % 64 == 0)
+#pragma unroll
+      for (int pass = 0; pass < kEncTmT / 32; ++pass) {
+        const int r = r0 + 32 * pass, t = t0 + r;
+        const float4 v = t < T ? *reinterpret_cast<const float4*>(src + (size_t)t * Mpad) : float4{0.f, 0.f, 0.f, 0.f};
+        tile[c][mq][r] = v.x;
+        tile[c][mq + 1][r] = v.y;
+        tile[c][mq + 2][r] = v.z;
+        tile[c][mq + 3][r] = v.w;
+      }
+    }
+  }
+  __syncthreads();
+  auto quantise = [&](float x) {
+    const float ratio = __fdiv_rn(x, mx);
+    int lo = 0, hi = 255;  // count of v with ratio < thr[v] (thr descending): binary search, 8 steps
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+      const int mid = (lo + hi) >> 1;
+      if (ratio < thr_s[mid]) lo = mid + 1; else hi = mid;
+    }
+    return (unsigned)lo;
+  };
+  // out: thread (mel bin of 8, four consecutive frames of the tile's 128): four passes over the tile's 32 mel bins
+  const int tq = 4 * (threadIdx.x & 31), mr0 = threadIdx.x >> 5;
+  const bool aligned = (T & 3) == 0;
+#pragma unroll
+  for (int pass = 0; pass < kEncTmM / 8; ++pass) {
+    const int ml = mr0 + 8 * pass, m = m0 + ml, t = t0 + tq;
+    if (m >= M || t >= T) continue;
+    unsigned q[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int c = 0; c < C; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(&tile[c][ml][tq]);
+      q[c][0] = quantise(v.x); q[c][1] = quantise(v.y); q[c][2] = quantise(v.z); q[c][3] = quantise(v.w);
+    }
+    unsigned char px[12];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (C == 1) { px[3 * p] = px[3 * p + 1] = px[3 * p + 2] = (unsigned char)q[0][p]; }
+      else { px[3 * p] = 0; px[3 * p + 1] = (unsigned char)q[0][p]; px[3 * p + 2] = (unsigned char)q[1][p]; }
+    }
+    uint8_t* __restrict__ dst8 = img + ((n * M + (size_t)(M - 1 - m)) * T + t) * 3;  // image row h shows mel bin M - 1 - h
+    if (aligned) {
+      unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(dst8);
+#pragma unroll
+      for (int wd = 0; wd < 3; ++wd)
+        dst[wd] = (unsigned)px[4 * wd] | ((unsigned)px[4 * wd + 1] << 8) | ((unsigned)px[4 * wd + 2] << 16) | ((unsigned)px[4 * wd + 3] << 24);
+    } else {
+      const int npx = min(4, T - t);
+      for (int b = 0; b < 3 * npx; ++b) dst8[b] = px[b];
+    }
+  }
+}
+
 // ---- PCM tail: audio_util.audio_from_waveform (:22-28).  wave (N*C, L) float32 -> pcm (N, L, C) int16,
 // samples * float32(32767 / max|clip|) truncated toward zero.
 __global__ void __launch_bounds__(256) pcm16_kernel(const float* __restrict__ wave, const float* __restrict__ clip_peak,
@@ -183,6 +252,12 @@ hipError_t launch_image_encode(const float* mel, const float* clip_max, const fl
                                int C, hipStream_t s) {
   const int bx = (T + 4 * 128 - 1) / (4 * 128);
   hipLaunchKernelGGL(image_encode_kernel, dim3(bx < 1 ? 1 : bx, M, N), dim3(128), 0, s, mel, clip_max, thr, img, M, T, C);
+  return hipGetLastError();
+}
+hipError_t launch_image_encode_tm(const float* mel_tm, const unsigned* max_keys, const float* clip_max_in, const float* thr, uint8_t* img,
+                                  float* clip_max_out, int N, int M, int Mpad, int T, int C, hipStream_t s) {
+  hipLaunchKernelGGL(image_encode_tm_kernel, dim3((T + kEncTmT - 1) / kEncTmT, (M + kEncTmM - 1) / kEncTmM, N), dim3(256), 0, s, mel_tm,
+                     max_keys, clip_max_in, thr, img, clip_max_out, M, Mpad, T, C);
   return hipGetLastError();
 }
 hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s) {

@@ -309,6 +309,14 @@ hipError_t launch_fam_repack(const float* plain, float* slots, const int* bin_of
 
 // image / PCM codecs
 hipError_t launch_image_decode(const uint8_t* img, const float* lut, float* out, int N, int H, int W, int C, hipStream_t s);
+// order-preserving integer key of a float for atomicMax: positive NaN is the largest key (np.max's NaN propagation comes for free),
+// key 0 is below every value
+__device__ __forceinline__ unsigned max_key(float v) {
+  unsigned b = __float_as_uint(v);
+  if (v != v) b = 0x7FC00000u;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 hipError_t launch_clip_max(const float* x, float* out, int nclips, size_t count, bool abs_value, hipStream_t s);
 hipError_t launch_image_encode(const float* mel, const float* clip_max, const float* thr, uint8_t* img, int N, int M, int T,
                                int C, hipStream_t s);

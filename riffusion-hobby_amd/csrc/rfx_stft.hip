@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
     }
   };
   if constexpr (PK && kFwdIdxRegs) load_pk_tables();
+  unsigned runmax = 0;  // key of the largest mel amplitude this thread has formed (0: below every value)
   __syncthreads();  // tw2 table in LDS
 
   for (int fr = f0; fr < f1; ++fr) {
@@ -530,13 +531,20 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
 #else
       const float s0 = filter_sum(seg[0][0], seg[0][1]);
       if (threadIdx.x < a.Mpad) row[threadIdx.x] = s0;  // padding filters (m >= M): empty segments, 0
+      if (a.max_keys && threadIdx.x < a.M) runmax = max(runmax, max_key(s0));
       if (second) {
         const float s1 = filter_sum(seg[1][0], seg[1][1]);
         if (threadIdx.x + kThreads < a.Mpad) row[threadIdx.x + kThreads] = s1;
+        if (a.max_keys && threadIdx.x + kThreads < a.M) runmax = max(runmax, max_key(s1));
       }
 #endif
     }
     __syncthreads();  // the next frame's P1 overwrites the products
+  }
+  if (a.max_keys) {  // image_from_spectrogram's maximum over the image's channels (image_util.py:41), see StftMelArgs::max_keys
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) runmax = max(runmax, (unsigned)__shfl_xor((int)runmax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&a.max_keys[clip / a.max_group], runmax);
   }
 }
 
@@ -572,7 +580,8 @@ hipError_t launch_stft_mel(const StftMelArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((stft_mel2_kernel<kKbMaskAll, false>), grid, block, kFrameDynLdsBytes, stream, a);
   else hipLaunchKernelGGL(stft_mel_kernel, grid, block, kFrameDynLdsBytes, stream, a);
   const hipError_t e = hipGetLastError();
-  return e != hipSuccess ? e : launch_mel_transpose(a.mel_tm, a.mel, a.B, a.T, a.M, a.Mpad, stream);
+  if (e != hipSuccess || !a.mel) return e;  // (no (B, M, T) copy wanted: rfx_image_from_waveform encodes from the frame-major scratch)
+  return launch_mel_transpose(a.mel_tm, a.mel, a.B, a.T, a.M, a.Mpad, stream);
 }
 
 hipError_t prepare_frame_kernels() {

@@ -107,6 +107,8 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     ),
     "rfx_image_decode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rfx_image_encode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rfx_image_from_waveform_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "rfx_image_from_waveform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rfx_pcm16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
@@ -480,6 +482,29 @@ class Plan:
         img = torch.empty((N, M, Tn, 3), dtype=torch.uint8, device=mel.device)
         mx = torch.empty((N,), dtype=torch.float32, device=mel.device)
         check(self.lib.rfx_image_encode_u8(mel.data_ptr(), N, M, Tn, int(stereo), thresholds.data_ptr(), mx.data_ptr(), img.data_ptr(), self._stream()))
+        return img, mx
+
+    def image_from_waveform(self, wave: torch.Tensor, stereo: bool, thresholds: torch.Tensor):
+        """spectrogram_image_converter.py:30-51 on the device: (N*C, Lw) float32 -> ((N, n_mels, T, 3) uint8, per-clip max (N,));
+        `mel_from_waveform` + `image_encode` in one call, byte for byte, without the (N*C, n_mels, T) tensor in between."""
+        wave = self._chk(wave, torch.float32)
+        thresholds = self._chk(thresholds, torch.float32)
+        C = 2 if stereo else 1
+        NC, Lw = wave.shape
+        if NC % C:
+            raise ValueError("batch must be a multiple of the channel count")
+        if Lw <= self.n_fft // 2:
+            raise RuntimeError(
+                f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                f"but got: padding ({self.n_fft // 2}, {self.n_fft // 2}) at dimension 2 of input {list(wave.shape)}"
+            )
+        N = NC // C
+        Tn = self.lib.rfx_stft_frames(self.handle, Lw)
+        ws = torch.empty(self.lib.rfx_image_from_waveform_workspace_bytes(self.handle, N, int(stereo), Lw), dtype=torch.uint8, device=wave.device)
+        img = torch.empty((N, self.n_mels, Tn, 3), dtype=torch.uint8, device=wave.device)
+        mx = torch.empty((N,), dtype=torch.float32, device=wave.device)
+        check(self.lib.rfx_image_from_waveform(self.handle, wave.data_ptr(), N, int(stereo), Lw, thresholds.data_ptr(), mx.data_ptr(),
+                                               img.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return img, mx
 
     def pcm16(self, wave: torch.Tensor, channels: int, normalize: bool = True, out: T.Optional[torch.Tensor] = None):

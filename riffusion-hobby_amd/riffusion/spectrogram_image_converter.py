@@ -74,9 +74,9 @@ class SpectrogramImageConverter:
         N, C, L = waveforms.shape
         if C != (2 if self.p.stereo else 1):
             raise ValueError(f"expected {2 if self.p.stereo else 1} channel(s), got {C}")
-        mel = plan.mel_from_waveform(waveforms.reshape(N * C, L).to(conv.device))
         thr = torch.from_numpy(image_util.encode_thresholds(float(self.p.power_for_image))).to(conv.device)
-        img, mx = plan.image_encode(mel, self.p.stereo, thr)
+        # one call (rfx_image_from_waveform): the mel amplitudes go from the forward kernel to the encoder without the (N*C, M, T) tensor
+        img, mx = plan.image_from_waveform(waveforms.reshape(N * C, L).to(conv.device, torch.float32), self.p.stereo, thr)
         img_np, mx_np = img.cpu().numpy(), mx.cpu().numpy()
         return [Image.fromarray(a, mode="RGB") for a in img_np], mx_np
 

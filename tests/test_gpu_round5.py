@@ -124,3 +124,60 @@ def test_line_form_group_kernel_on_banks_with_long_groups(O, kw, unit):
     a = plan.unpack_magnitudes(plan.inverse_mel(mel.cuda(), C, seed=1), C, T)
     b = plan.unpack_magnitudes(plan.inverse_mel(mel.cuda(), C, seed=2), C, T)
     assert bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0 and not torch.equal(a, b)
+
+
+# ---- round 5: spectrogram_image_from_audio in one call (rfx_image_from_waveform) and the forward kernel's packed tables
+FWD_CASES = [
+    # (SpectrogramParams keywords, stereo, clips, frames): engines and banks the forward path knows
+    ({}, False, 3, 512),                                                   # 44.1 kHz, default bank: product form, packed tables
+    ({}, True, 2, 130),                                                    # stereo: the maximum spans an image's two channels
+    ({}, False, 2, 101),                                                   # T % 4 != 0: the byte-wise tail of the encoder
+    ({"max_frequency": 20000, "min_frequency": 20}, False, 2, 64),         # a bank over every kb (plain tables)
+    ({"num_frequencies": 700, "max_frequency": 10000}, False, 1, 40),      # wider than the product form takes: table form, maximum by a pass
+    ({"sample_rate": 48000, "max_frequency": 10000}, True, 2, 72),         # row family
+    ({"sample_rate": 11025, "max_frequency": 5000}, False, 2, 50),         # generic engine
+]
+
+
+@pytest.mark.parametrize("kw,stereo,N,Tn", FWD_CASES)
+def test_image_from_waveform_equals_the_two_calls_byte_for_byte(kw, stereo, N, Tn):
+    """spectrogram_image_converter.py:30-51.  rfx_image_from_waveform leaves out the (N*C, n_mels, T) tensor and the pass for its
+    maximum; what comes out must be what rfx_mel_from_waveform + rfx_image_encode_u8 give: same bytes, same MAX_VALUE bits."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import image_util
+
+    p = SpectrogramParams(stereo=stereo, **kw)
+    plan = _hip.get_plan(p, "cuda")
+    C = 2 if stereo else 1
+    g = torch.Generator(device="cuda").manual_seed(77 + Tn)
+    wave = torch.randn(N * C, p.hop_length * (Tn - 1), device="cuda", generator=g) * 6000.0
+    wave[0, : wave.shape[1] // 3] *= 1e-3  # a quiet stretch: small ratios, the far end of the threshold table
+    thr = torch.from_numpy(image_util.encode_thresholds(float(p.power_for_image))).cuda()
+    mel = plan.mel_from_waveform(wave)
+    img2, mx2 = plan.image_encode(mel, stereo, thr)
+    img1, mx1 = plan.image_from_waveform(wave, stereo, thr)
+    assert img1.shape == img2.shape == (N, p.num_frequencies, Tn, 3)
+    assert torch.equal(mx1.view(torch.int32), mx2.view(torch.int32)), (mx1, mx2)
+    assert torch.equal(img1, img2), f"{int((img1 != img2).sum())} bytes differ"
+    assert int(img1.max()) > 0 and len(torch.unique(img1)) > 50  # (a real picture, not a constant)
+
+
+def test_forward_kernel_with_packed_tables_against_the_dense_definition(plan):
+    """The default-bank forward kernel reads its product positions as packed 16-bit LDS addresses, derives nine of its twenty
+    twiddles and keeps a sliding input window (csrc/rfx_stft.hip, round 5): |STFT| through torch.stft times the dense filterbank
+    is the definition (spectrogram_converter.py:165-185); clips of different lengths exercise runs of 1 .. 64 frames (a clip needs more than n_fft / 2 samples: 22 frames)."""
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    p = SpectrogramParams()
+    win = torch.hann_window(p.win_length, device="cuda")
+    for B, Tn in ((1, 23), (2, 77), (5, 512)):
+        g = torch.Generator(device="cuda").manual_seed(B * 1000 + Tn)
+        wave = torch.randn(B, p.hop_length * (Tn - 1), device="cuda", generator=g) * 8000.0
+        mel = plan.mel_from_waveform(wave)
+        ref = torch.stft(wave.double(), p.n_fft, p.hop_length, p.win_length, win.double(), center=True, pad_mode="reflect", return_complex=True).abs()
+        ref_mel = (ref.transpose(1, 2) @ plan.melfb.cuda().double()).transpose(1, 2)
+        rel = float(torch.linalg.norm(mel.double() - ref_mel) / torch.linalg.norm(ref_mel))
+        worst = float(((mel.double() - ref_mel).abs() / (ref_mel.abs() + 1e-3 * ref_mel.abs().max())).max())
+        print(f"forward kernel, B = {B}, T = {Tn}: rel-L2 {rel:.2e} against the float64 dense definition, worst relative entry {worst:.2e}")
+        assert rel < 5e-7 and worst < 1e-4
