@@ -415,7 +415,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
     for (int i = 0; i < f.rb; ++i)
       for (int q = 1; q < f.ra; ++q) {
         const int e = (i * q) % f.h;
-        twa[(size_t)i * (f.ra - 1) + q - 1] = cf{(float)cos(PI2 * e / (double)f.h), (float)(-sin(PI2 * e / (double)f.h))};
+        twa[(size_t)(q - 1) * f.rb + i] = cf{(float)cos(PI2 * e / (double)f.h), (float)(-sin(PI2 * e / (double)f.h))};
       }
     RFX_HIP(hipMalloc(&pl->d_fam_tw, tw.size() * sizeof(cf)));
     RFX_HIP(hipMemcpy(pl->d_fam_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));

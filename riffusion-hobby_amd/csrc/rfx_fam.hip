@@ -55,6 +55,12 @@ constexpr int fam_threads(int ra, int rb, int nr = 40) {
 #ifndef RFX_FAM_TW_EARLY
 #define RFX_FAM_TW_EARLY 0
 #endif
+#ifndef RFX_FAM_GL_STREAM_FWD
+#define RFX_FAM_GL_STREAM_FWD true  // 48 kHz Griffin-Lim kernel: streamed radix-24 pass A (rfx_fam_core.h) - forward 38.3 -> 37.7 ms per 64 tiles x 32 iterations, inverse 39.8: off
+#endif
+#ifndef RFX_FAM_GL_STREAM_INV
+#define RFX_FAM_GL_STREAM_INV false
+#endif
 #ifndef RFX_FAM_STORE_AUX
 #define RFX_FAM_STORE_AUX 0  // cache policy of the synthesis-frame stores (the fold reads them back once)
 #endif
@@ -76,23 +82,34 @@ size_t fam_static_lds_bytes(const FamGeom& g) { return fam_twiddles_in_lds(g.ra,
 #endif
 
 // the thread's RA - 1 pass-A twiddles, fetched in two batches
-template <int RA, bool LDS>
+template <int RA, int RB, bool LDS>
 struct FamTwA {
   cf w[RA];
   rsrc_t src;
   unsigned voff;
-  const cf* tab;  // LDS row of this thread
-  template <int HALF>
+  const cf* tab;  // LDS column of this thread (entry p - 1 at (p - 1) RB)
+  template <bool INV, int BATCH, bool STREAM = false>  // the twiddles of batch BATCH of the forward / inverse pass (rfx_fam_core.h::fam_tw_in_batch)
   __device__ __forceinline__ void load() {
 #pragma unroll
-    for (int p = HALF ? RA / 2 + 1 : 1; p < (HALF ? RA : RA / 2 + 1); ++p) {
+    for (int p = 1; p < RA; ++p) {
+      if (!fam_tw_in_batch(RA, INV, STREAM, BATCH, p)) continue;
+#if defined(RFX_FAM_ABL) && RFX_FAM_ABL >= 1  // timing ablation (wrong results): no pass-A twiddle fetches
+      w[p] = cf{1.f, (float)p};
+      continue;
+#endif
       if (LDS) {
-        w[p] = tab[p - 1];
+        w[p] = tab[(p - 1) * RB];
       } else {
-        const v2f t = ld2(src, voff, (unsigned)(p - 1) * 8u);
+        const v2f t = ld2(src, voff, (unsigned)(p - 1) * (RB * 8u));
         w[p] = cf{t.x, t.y};
       }
     }
+  }
+  template <bool INV, bool STREAM = false>
+  __device__ __forceinline__ void load_batch(int b) {  // b >= 1 is a compile-time constant wherever this is called (unrolled stages)
+    if (b == 1) load<INV, 1, STREAM>();
+    if (fam_tw_batches(RA, INV, STREAM) > 2 && b == 2) load<INV, 2, STREAM>();
+    if (fam_tw_batches(RA, INV, STREAM) > 3 && b == 3) load<INV, 3, STREAM>();
   }
 };
 
@@ -136,14 +153,21 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
   if (TWL)
     for (int i = tid; i < RB * (RA - 1); i += NT) twa_lds[i] = a.twa[i];
   __syncthreads();  // the first pass-A read of the frame loop may precede the loop's first barrier, and reads other waves' entries
-  FamTwA<RA, TWL> wa;
+  FamTwA<RA, RB, TWL> wa;
   wa.src = make_rsrc(a.twa, (size_t)RB * (RA - 1) * sizeof(cf));
-  wa.voff = (unsigned)iA * ((RA - 1) * 8u);
-  wa.tab = twa_lds + iA * (RA - 1);
+  wa.voff = (unsigned)iA * 8u;
+  wa.tab = twa_lds + iA;
   // g(n')^k1 for k1 = 1..10 and 20 only (fam_g_pow)
   cf w1[12];
   float wv[WH], u[WH];
   auto load_tables = [&] {
+#if defined(RFX_FAM_ABL) && RFX_FAM_ABL >= 2  // timing ablation (wrong results): no g^k1 / Hann fetches either
+#pragma unroll
+    for (int k = 1; k <= (NR == 40 ? 11 : 10); ++k) w1[k] = cf{1.f, (float)k};
+#pragma unroll
+    for (int j = 0; j < WH; ++j) wv[j] = (float)j;
+    return;
+#endif
 #pragma unroll
     for (int k = 1; k <= (NR == 40 ? 11 : 10); ++k) {
       const v2f t = ld2(tw1, npr8, (unsigned)(k <= 10 ? k : 20) * (H * 8u));
@@ -187,17 +211,17 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
     if (MODE != 0) {
       if (act1) fam_p1_forward_store<NR>(u, g1, cube, col, rs);
       RFX_SCHED_FENCE();
-      wa.template load<0>();
+      wa.template load<false, 0, RFX_FAM_GL_STREAM_FWD>();
 #if RFX_FAM_TW_EARLY
-      wa.template load<1>();
+      for (int b = 1; b < fam_tw_batches(RA, false, RFX_FAM_GL_STREAM_FWD); ++b) wa.template load_batch<false, RFX_FAM_GL_STREAM_FWD>(b);
 #endif
       FSTAMP(1);
       __syncthreads();
       FSTAMP(2);
       RFX_SCHED_FENCE();
       if (actA)
-        fam_pass_a_forward<RA, RB>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int half) {
-          if (half == 1 && !RFX_FAM_TW_EARLY) wa.template load<1>();
+        fam_pass_a_forward<RA, RB, RFX_FAM_GL_STREAM_FWD>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int batch) {
+          if (!RFX_FAM_TW_EARLY) wa.template load_batch<false, RFX_FAM_GL_STREAM_FWD>(batch);
           RFX_SCHED_FENCE();
         });
       RFX_SCHED_FENCE();
@@ -232,14 +256,14 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
     __builtin_amdgcn_s_setprio(0);
 #endif
     RFX_SCHED_FENCE();
-    wa.template load<0>();
+    wa.template load<true, 0, RFX_FAM_GL_STREAM_INV>();
     FSTAMP(4);
     __syncthreads();
     FSTAMP(2);
     RFX_SCHED_FENCE();
     if (actA)
-      fam_pass_a_inverse<RA, RB>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int half) {
-        if (half == 1) wa.template load<1>();
+      fam_pass_a_inverse<RA, RB, RFX_FAM_GL_STREAM_INV>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int batch) {
+        wa.template load_batch<true, RFX_FAM_GL_STREAM_INV>(batch);
         RFX_SCHED_FENCE();
       });
     RFX_SCHED_FENCE();
@@ -319,10 +343,10 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
   if (TWL)
     for (int i = tid; i < RB * (RA - 1); i += NT) twa_lds[i] = a.twa[i];
   __syncthreads();  // as in fam_gl_kernel: the table must be complete before the first pass A
-  FamTwA<RA, TWL> wa;
+  FamTwA<RA, RB, TWL> wa;
   wa.src = make_rsrc(a.twa, (size_t)RB * (RA - 1) * sizeof(cf));
-  wa.voff = (unsigned)iA * ((RA - 1) * 8u);
-  wa.tab = twa_lds + iA * (RA - 1);
+  wa.voff = (unsigned)iA * 8u;
+  wa.tab = twa_lds + iA;
   cf w1[12];
   float wv[WH], u[WH];
   auto g1 = [&w1](int k) { return fam_g_pow(w1, k); };
@@ -346,12 +370,12 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
     for (int j = 0; j < WH; ++j) u[j] *= wv[j];
     if (act1) fam_p1_forward_store<NR>(u, g1, cube, col, rs);
     RFX_SCHED_FENCE();
-    wa.template load<0>();
+    wa.template load<false, 0, true>();
     __syncthreads();
     RFX_SCHED_FENCE();
     if (actA)
-      fam_pass_a_forward<RA, RB>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int half) {
-        if (half == 1) wa.template load<1>();
+      fam_pass_a_forward<RA, RB, true>(rowa, 0, [&wa](int p) { return wa.w[p]; }, [&wa](int batch) {
+        wa.template load_batch<false, true>(batch);
         RFX_SCHED_FENCE();
       });
     RFX_SCHED_FENCE();

@@ -166,39 +166,109 @@ RFX_HD void fam_p1_load_inverse(const cf* cube, TW tw1, float (&y)[NR / 4], int 
   else p1_inverse_rows20(raw, fix, y);
 }
 
-// ---- pass A: thread (row, i).  tw(p) = W_h^{i p}, p = 1..RA-1.  `stage(0)` runs once the row values are requested and
-// `stage(1)` once the outputs 0..RA/2 have been stored: the kernels fetch the twiddles 1..RA/2 / RA/2+1..RA-1 there (two
-// batches of registers instead of 2 (RA - 1) next to the butterfly's own 4 RA).
-template <int RA, int RB, class TW, class STAGE = NoStage>
-RFX_HD void fam_pass_a_forward(cf* row, int i, TW tw, STAGE stage = STAGE()) {
-  cf v[RA], y[RA];
-  const cf none[RA] = {};
-#pragma unroll
-  for (int q = 0; q < RA; ++q) v[q] = row[i + q * RB];
-  stage(0);
-  gen_dft<RA, false>(v, y, none);
-  row[i] = y[0];
-#pragma unroll
-  for (int p = 1; p <= RA / 2; ++p) row[i + p * RB] = cmul(y[p], tw(p));
-  stage(1);
-#pragma unroll
-  for (int p = RA / 2 + 1; p < RA; ++p) row[i + p * RB] = cmul(y[p], tw(p));
+// ---- pass A: thread (row, i).  tw(p) = W_h^{i p}, p = 1..RA-1, used batch by batch.
+// Twiddle batches.  Every radix but 24: two halves, p = 1 .. (RA-1)/2 | the rest, for both directions.  RA = 24 (48 kHz) streams
+// its butterfly instead (below) and wants the twiddles in the order the 8 x 3 decomposition produces / consumes them:
+//   forward (DIF): the second stage emits the outputs p = k1 + 8 k2 pair of k1 by pair of k1  -> four batches, p in batch (p % 8) / 2
+//   inverse (DIT): the first stage takes the inputs p = 3 n1 + n2 column n2 by column n2      -> three batches, p in batch p % 3
+constexpr int fam_tw_batches(int ra, bool inv, bool stream) { return ra == 24 && stream ? (inv ? 3 : 4) : 2; }
+constexpr bool fam_tw_in_batch(int ra, bool inv, bool stream, int batch, int p) {
+  if (ra == 24 && stream) return inv ? p % 3 == batch : (p % 8) / 2 == batch;
+  return batch == 0 ? p <= ra / 2 : p > ra / 2;
 }
-// inverse: the twiddles come first.  `stage(0)` before the first half is read, `stage(1)` before the second
-template <int RA, int RB, class TW, class STAGE = NoStage>
+// `stage(0)` runs once the first row values are requested, `stage(b)` (b >= 1) right before batch b's twiddles are needed - the
+// kernels fetch them there: batches of registers instead of 2 (RA - 1) next to the butterfly's own 4 RA.
+template <int RA, int RB, bool STREAM = false, class TW, class STAGE = NoStage>
+RFX_HD void fam_pass_a_forward(cf* row, int i, TW tw, STAGE stage = STAGE()) {
+  if constexpr (RA == 24 && STREAM) {
+    // The 24-point butterfly as gen_dft_ct<8, 3> does it, value for value, but streamed: the row is read one column of eight at a
+    // time and the outputs leave as soon as their 3-point butterfly is done, so 24 intermediate values and one column are alive
+    // instead of 24 inputs + 24 intermediates + 24 outputs (the 48 kHz kernels held 88 - 132 B of scratch until round 5).  In place:
+    // every input has been read before the first output is stored (the thread owns exactly these 24 elements).
+    cf t[3][8];
+    const cf none8[8] = {}, none3[3] = {};
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) {
+      cf a[8], b[8];
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) a[n1] = row[i + (3 * n1 + n2) * RB];
+      if (n2 == 0) stage(0);
+      gen_dft<8, false>(a, b, none8);
+#pragma unroll
+      for (int k1 = 0; k1 < 8; ++k1) t[n2][k1] = gen_const_twiddle<24, false>(b[k1], n2 * k1);
+      RFX_SCHED_FENCE();  // (left alone the compiler requests all 24 inputs first)
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+      if (k1 > 0 && k1 % 2 == 0) stage(k1 / 2);
+      cf a[3] = {t[0][k1], t[1][k1], t[2][k1]}, b[3];
+      gen_dft<3, false>(a, b, none3);
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) {
+        const int p = k1 + 8 * k2;
+        row[i + p * RB] = p == 0 ? b[0] : cmul(b[k2], tw(p));
+      }
+    }
+  } else {
+    cf v[RA], y[RA];
+    const cf none[RA] = {};
+#pragma unroll
+    for (int q = 0; q < RA; ++q) v[q] = row[i + q * RB];
+    stage(0);
+    gen_dft<RA, false>(v, y, none);
+    row[i] = y[0];
+#pragma unroll
+    for (int p = 1; p < RA; ++p)
+      if (fam_tw_in_batch(RA, false, false, 0, p)) row[i + p * RB] = cmul(y[p], tw(p));
+    stage(1);
+#pragma unroll
+    for (int p = 1; p < RA; ++p)
+      if (fam_tw_in_batch(RA, false, false, 1, p)) row[i + p * RB] = cmul(y[p], tw(p));
+  }
+}
+// inverse: the twiddles come first.  `stage(b)` runs before batch b is read
+template <int RA, int RB, bool STREAM = false, class TW, class STAGE = NoStage>
 RFX_HD void fam_pass_a_inverse(cf* row, int i, TW tw, STAGE stage = STAGE()) {
-  cf v[RA], y[RA];
-  const cf none[RA] = {};
-  stage(0);
-  v[0] = row[i];
+  if constexpr (RA == 24 && STREAM) {  // streamed like the forward pass: one column of eight inputs (and its eight twiddles) at a time
+    cf t[3][8];
+    const cf none8[8] = {}, none3[3] = {};
 #pragma unroll
-  for (int p = 1; p <= RA / 2; ++p) v[p] = cmulc(row[i + p * RB], tw(p));
-  stage(1);
+    for (int n2 = 0; n2 < 3; ++n2) {
+      stage(n2);
+      cf a[8], b[8];
 #pragma unroll
-  for (int p = RA / 2 + 1; p < RA; ++p) v[p] = cmulc(row[i + p * RB], tw(p));
-  gen_dft<RA, true>(v, y, none);
+      for (int n1 = 0; n1 < 8; ++n1) {
+        const int p = 3 * n1 + n2;
+        a[n1] = p == 0 ? row[i] : cmulc(row[i + p * RB], tw(p));
+      }
+      gen_dft<8, true>(a, b, none8);
 #pragma unroll
-  for (int q = 0; q < RA; ++q) row[i + q * RB] = y[q];
+      for (int k1 = 0; k1 < 8; ++k1) t[n2][k1] = gen_const_twiddle<24, true>(b[k1], n2 * k1);
+      RFX_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+      cf a[3] = {t[0][k1], t[1][k1], t[2][k1]}, b[3];
+      gen_dft<3, true>(a, b, none3);
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) row[i + (k1 + 8 * k2) * RB] = b[k2];
+    }
+  } else {
+    cf v[RA], y[RA];
+    const cf none[RA] = {};
+    stage(0);
+    v[0] = row[i];
+#pragma unroll
+    for (int p = 1; p < RA; ++p)
+      if (fam_tw_in_batch(RA, true, false, 0, p)) v[p] = cmulc(row[i + p * RB], tw(p));
+    stage(1);
+#pragma unroll
+    for (int p = 1; p < RA; ++p)
+      if (fam_tw_in_batch(RA, true, false, 1, p)) v[p] = cmulc(row[i + p * RB], tw(p));
+    gen_dft<RA, true>(v, y, none);
+#pragma unroll
+    for (int q = 0; q < RA; ++q) row[i + q * RB] = y[q];
+  }
 }
 
 // ---- pass B: thread (row, p).  R[s] = slot k1 + 40 (p + RA s).  `row` points at the thread's RB contiguous elements; with

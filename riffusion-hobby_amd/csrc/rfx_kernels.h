@@ -270,7 +270,8 @@ struct FamGlArgs {
   float* frames;         // [B*T][fpitch] windowed, scaled synthesis frames, window sample j at fshift + j (GenGeom::fpitch / fshift)
   int fpitch, fshift;
   const cf* tw1;         // [21][h]      g(n')^k1
-  const cf* twa;         // [rb][ra-1]   W_h^{i p}
+  const cf* twa;         // [ra-1][rb]   W_h^{i p} at [p - 1][i]: the lanes of a wave (consecutive i) read consecutive entries (round 5; [rb][ra-1] until
+                         // then: 29 cache lines per wave-wide load, which cost the 48 kHz kernels a fifth of their time)
   const float* win;      // [win]
   float mom;             // momentum / (1 + momentum)
   unsigned long long seed;

@@ -8,6 +8,7 @@
 using namespace rfx;
 
 namespace {
+int g_stream_fwd = 1, g_stream_inv = 0;  // which form of the radix-24 pass A runs (emu_fam_set_stream)
 struct FamTables {
   std::vector<cf> tw1, twa;
 };
@@ -23,7 +24,7 @@ void make_tables(const FamGeom& g, FamTables& t) {
   for (int i = 0; i < g.rb; ++i)
     for (int p = 1; p < g.ra; ++p) {
       const int e = (i * p) % g.h;
-      t.twa[(size_t)i * (g.ra - 1) + p - 1] = cf{(float)cos(PI2 * e / (double)g.h), (float)(-sin(PI2 * e / (double)g.h))};
+      t.twa[(size_t)(p - 1) * g.rb + i] = cf{(float)cos(PI2 * e / (double)g.h), (float)(-sin(PI2 * e / (double)g.h))};
     }
 }
 template <int RA, int RB, int NR>
@@ -39,7 +40,9 @@ void forward(const FamGeom& g, const FamTables& t, const float* win_samples, std
   }
   for (int tid = 0; tid < ROWS * RB; ++tid) {  // pass A
     const int row = tid / RB, i = tid % RB;
-    fam_pass_a_forward<RA, RB>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)i * (RA - 1) + p - 1]; });
+    // (the radix-24 pass exists plain and streamed: the kernels stream the forward pass and not the inverse one, the default here)
+    if (g_stream_fwd) fam_pass_a_forward<RA, RB, true>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)(p - 1) * RB + i]; });
+    else fam_pass_a_forward<RA, RB, false>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)(p - 1) * RB + i]; });
   }
   slots.assign((size_t)g.fsf, cf{0.f, 0.f});
   for (int tid = 0; tid < ROWS * RA; ++tid) {  // pass B
@@ -61,7 +64,8 @@ void inverse(const FamGeom& g, const FamTables& t, const std::vector<cf>& slots,
   }
   for (int tid = 0; tid < ROWS * RB; ++tid) {
     const int row = tid / RB, i = tid % RB;
-    fam_pass_a_inverse<RA, RB>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)i * (RA - 1) + p - 1]; });
+    if (g_stream_inv) fam_pass_a_inverse<RA, RB, true>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)(p - 1) * RB + i]; });
+    else fam_pass_a_inverse<RA, RB, false>(cube.data() + (size_t)row * g.rs, i, [&](int p) { return t.twa[(size_t)(p - 1) * RB + i]; });
   }
   const float sc = 2.0f / (float)g.n_fft;
   for (int n = 0; n < g.h; ++n) {
@@ -115,6 +119,7 @@ int run(const FamGeom& g, int dir, const float* in, float* out) {
 }  // namespace
 
 extern "C" {
+void emu_fam_set_stream(int fwd, int inv) { g_stream_fwd = fwd; g_stream_inv = inv; }
 // dir 0: forward, dir 1: inverse; rs_pad: extra LDS elements between cube rows (the kernels pad by up to 7)
 int emu_fam_transform(int n_fft, int dir, int rs_pad, const float* in, float* out) {
   FamGeom g;

@@ -99,3 +99,28 @@ def test_griffinlim_on_the_emulated_kernels_matches_the_oracle(emu, rate, hop_ms
     snr = 10 * np.log10(np.sum(want.astype(np.float64) ** 2) / np.sum((want.astype(np.float64) - out) ** 2))
     print(f"{rate} Hz, hop {op.hop_length}, T = {T}: emulated row-family Griffin-Lim n_iter={n_iter}: {snr:.1f} dB vs the oracle")
     assert snr >= (110.0 if n_iter == 0 else 90.0)
+
+
+def test_streamed_radix_24_pass_equals_the_plain_one_bit_for_bit(emu):
+    """48 kHz: the 24-point butterfly of pass A streamed column by column (rfx_fam_core.h, round 5: what the kernels run in the
+    forward direction) against the plain gen_dft<24> form - same operations, same order, so the same bits on the host."""
+    n_fft = 19200
+    rng = np.random.default_rng(5)
+    u = (rng.standard_normal(n_fft // 4) * 100).astype(np.float32)
+    X = (rng.standard_normal(n_fft // 2 + 1) + 1j * rng.standard_normal(n_fft // 2 + 1)).astype(np.complex64)
+    X[0] = X[0].real
+    X[-1] = X[-1].real
+    res = {}
+    try:
+        for fwd, inv in ((0, 0), (1, 1)):
+            emu.emu_fam_set_stream(fwd, inv)
+            spec = np.zeros(n_fft // 2 + 1, np.complex64)
+            back = np.zeros(n_fft // 4, np.float32)
+            assert emu.emu_fam_transform(n_fft, 0, 0, u.ctypes.data_as(FP), spec.view(np.float32).ctypes.data_as(FP)) == 0
+            assert emu.emu_fam_transform(n_fft, 1, 0, X.view(np.float32).ctypes.data_as(FP), back.ctypes.data_as(FP)) == 0
+            res[(fwd, inv)] = (spec.copy(), back.copy())
+    finally:
+        emu.emu_fam_set_stream(1, 0)
+    assert np.array_equal(res[(0, 0)][0].view(np.uint32), res[(1, 1)][0].view(np.uint32))
+    assert np.array_equal(res[(0, 0)][1].view(np.uint32), res[(1, 1)][1].view(np.uint32))
+
