@@ -411,17 +411,22 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
       // banded mel projection straight from the frame in LDS (the reference multiplies the dense filterbank,
       // spectrogram_converter.py:76-84, :185): a filter's weights come eight at a time from the L2-resident table, summed in
       // increasing bin order like gen_mel_kernel
+      // (buffer-descriptor addressing: SRD + one 32-bit lane offset - the 64-bit per-lane pointers of the first version were what the
+      // 48 kHz kernel spilled inside its frame loop)
+      const rsrc_t bw = make_rsrc(a.band_wt, 0xFFFFFFFFull), blo = make_rsrc(a.band_lo, (size_t)a.Mpad * 4), bln = make_rsrc(a.band_len, (size_t)a.Mpad * 4);
+      const rsrc_t mrow = make_rsrc(a.mel_tm + (size_t)gf * a.Mpad, (size_t)a.Mpad * 4);
+      const unsigned mstride = (unsigned)a.Mpad * 4u;
       for (int m = tid; m < a.Mpad; m += NT) {
         float acc = 0.f;
 #ifndef RFX_ABL_FAM_NOMEL  // (ablation: what the sum phase costs)
         if (m < a.M) {
-          const int lo = a.band_lo[m], n = a.band_len[m];
-          const float* __restrict__ wcol = a.band_wt + m;
+          const int lo = (int)ld1u(blo, (unsigned)m * 4u, 0), n = (int)ld1u(bln, (unsigned)m * 4u, 0);
           for (int i = 0; i < n; i += 8) {
             float w[8], v[8];
+            const unsigned woff = (unsigned)m * 4u + (unsigned)i * mstride;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              w[e] = wcol[(size_t)(i + e) * a.Mpad];
+              w[e] = ld1(bw, woff + (unsigned)e * mstride, 0);
               const int q = lo + i + e;
               v[e] = magl[q < n_stft ? q : n_stft - 1];  // (rows past the filter's end carry zero weights)
             }
@@ -432,7 +437,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
 #else
         acc = magl[m];
 #endif
-        a.mel_tm[(size_t)gf * a.Mpad + m] = acc;
+        st1(acc, mrow, (unsigned)m * 4u, 0);
       }
     } else if (MODE == 1) {
       cf* __restrict__ out = a.spec + (size_t)gf * fs;

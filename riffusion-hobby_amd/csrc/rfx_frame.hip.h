@@ -177,6 +177,10 @@ template <bool SHORT = false>
 __device__ __forceinline__ void load_tw1(Tw1& tw, const FrameCtx& f) {
 #pragma unroll
   for (int k = 1; k < (SHORT ? 12 : 21); ++k) {
+#if defined(RFX_FWD_ABL) && RFX_FWD_ABL == 8  // timing ablation of the forward kernel (wrong results): no twiddle fetches
+    tw.w[k] = cf{1.f, (float)k};
+    continue;
+#endif
     v2f w = ld2(f.tw1, f.npr8, (unsigned)(SHORT && k == 11 ? 20 : k) * (kHop * 8u));
     tw.w[k] = cf{w.x, w.y};
   }

@@ -275,11 +275,11 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) { 
 #define RFX_FWD_ABL 0  // timing ablations of -DRFX_ABLATION builds (wrong results): 2 no product scatter, 3 no segment sums,
 #endif                 // 4 transform + table fetches only, 5 no mel tables either
 #ifndef RFX_FWD_OPT
-#define RFX_FWD_OPT 31  // bit 0: packed mel tables (PK), bit 1: short twiddle table, bits 2-4 below
-#endif
+#define RFX_FWD_OPT 15  // bit 0: packed mel tables (PK), bit 1: short twiddle table, bits 2-4 below (bit 4 measured 0.503 -> 0.500 ms and
+#endif                  // costs the nine registers the running maximum of rfx_image_from_waveform needs: off)
 constexpr bool kFwdTwShort = (RFX_FWD_OPT & 2) != 0;
-constexpr bool kFwdWinRegs = (RFX_FWD_OPT & 4) != 0;  // the ten Hann samples stay in registers over the run
-constexpr bool kFwdSlide = (RFX_FWD_OPT & 8) != 0;    // sliding input window: one new sample per frame
+constexpr bool kFwdWinRegs = (RFX_FWD_OPT & 4) != 0;  // (kernels with ten contributing slots per thread: ) the ten Hann samples stay in registers over the run
+constexpr bool kFwdSlide = (RFX_FWD_OPT & 8) != 0;    // ... and the input is a sliding window: one new sample per frame
 constexpr bool kFwdIdxRegs = (RFX_FWD_OPT & 16) != 0; // PK: the packed positions / padding / segments stay in registers over the run
 template <unsigned KBMASK, bool PK>
 __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
@@ -288,6 +288,8 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   const FrameCtx f = frame_ctx(smem, t, a.tw1, a.tw2);
   float* prod = reinterpret_cast<float*>(smem);  // [0, kQPad): one dump float per lane, then w0 * |X|, group-padded; the same for w1 * |X| from prod_arr on
   constexpr int NKB = __builtin_popcount(KBMASK);
+  constexpr bool TWS = kFwdTwShort;
+  constexpr bool WIN_REGS = kFwdWinRegs && NKB <= 10, SLIDE = kFwdSlide && NKB <= 10;  // (the 21-slot form has no registers for them: 94 scratch instructions)
   static_assert(!PK || (KBMASK == kKbMaskLow && NKB == 10), "the packed tables hold ten slots per thread");
 
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
     for (int j = 0; j < 10; ++j) d[j] = load_x(fr + j - kHalfHops);
   };
   auto next_frame = [&](int fr) {  // the samples of frame fr, given those of frame fr - 1
-    if (kFwdSlide) {
+    if (SLIDE) {
 #pragma unroll
       for (int j = 0; j < 9; ++j) d[j] = d[j + 1];
       d[9] = load_x(fr + 9 - kHalfHops);
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   };
   load_frame(f0);
   Tw1 tw1;
-  load_tw1<kFwdTwShort>(tw1, f);
+  load_tw1<TWS>(tw1, f);
   // where the products go, this thread's zero-padding positions, and the segments of its (up to two) filters - threadIdx
   // and threadIdx + kThreads (the first wave carries the second filters: they are the LONGEST bands, its first filters
   // the shortest).  Plain form: float positions, one per dword; PK: byte addresses, two per dword (sat[i] = slots 2 i and
@@ -366,13 +368,13 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
     for (int j = 0; j < 10; ++j) u[j] = d[j] * w10[j];
     cf R[21];
     float sw0[21], sw1[21];  // per contributing slot: weights of its bin on its first / second filter, then their products with |X|
-    frame_forward_tw<kFwdTwShort>(u, R, f, t, tw1,
+    frame_forward_tw<TWS>(u, R, f, t, tw1,
                      NoHook(),
                      NoHook(),
                      [&] {  // before P3 (P2's registers are free): the slots' weights fly under P3
 #pragma unroll
                        for (int kb = 0; kb < 21; ++kb)
-                         if (RFX_FWD_ABL >= 5) {
+                         if (RFX_FWD_ABL >= 5 && RFX_FWD_ABL != 8) {  // (7: no slot weights only; 8: no twiddle fetches only)
                            sw0[kb] = 1.f;
                            sw1[kb] = 2.f;
                          } else if ((KBMASK >> kb) & 1u) {
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
       }
     // the mel phase's positions: needed right behind the next two barriers, in flight across them
     if constexpr (!(PK && kFwdIdxRegs)) {
-#if RFX_FWD_ABL >= 5
+#if RFX_FWD_ABL == 5 || RFX_FWD_ABL == 6
 #pragma unroll
     for (int i = 0; i < (PK ? 5 : 21); ++i) sat[i] = 0;
 #pragma unroll
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
     }
 #endif
     }
-#if RFX_FWD_ABL >= 4  // ablation: the transform and the table fetches only (no exchange, no sums; one barrier before the next P1)
+#if RFX_FWD_ABL >= 4 && RFX_FWD_ABL <= 6  // ablation: the transform and the table fetches only (no exchange, no sums; one barrier before the next P1)
     {
       float s = 0.f;
 #pragma unroll
@@ -425,8 +427,8 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
 #pragma unroll
       for (int i = 0; i < (PK ? 2 : kMelPadsPerThread); ++i) s += __builtin_bit_cast(float, pad_at[i]);
       s += __builtin_bit_cast(float, seg[0][0] + seg[0][1] + seg[1][0] + seg[1][1]);
-      load_tw1<kFwdTwShort>(tw1, f);
-      if (!kFwdWinRegs) load_window();
+      load_tw1<TWS>(tw1, f);
+      if (!WIN_REGS) load_window();
       next_frame(fr + 1);
       if (threadIdx.x < a.Mpad) a.mel_tm[((size_t)clip * a.T + fr) * a.Mpad + threadIdx.x] = s;
       __syncthreads();
@@ -479,8 +481,8 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
       prod[threadIdx.x & 63] = s;
     }
 #endif
-    load_tw1<kFwdTwShort>(tw1, f);  // for the next frame's P1: in flight across the mel phase
-    if (!kFwdWinRegs) load_window();
+    load_tw1<TWS>(tw1, f);  // for the next frame's P1: in flight across the mel phase
+    if (!WIN_REGS) load_window();
     next_frame(fr + 1);
     __syncthreads();
     {

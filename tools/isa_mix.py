@@ -14,7 +14,7 @@ import collections, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "riffusion-hobby_amd", "csrc")
 KERNELS = [("rfx_gl.hip", "_ZN3rfx14gl_iter_kernelILi2EEEvNS_6GlArgsE", "rfx::gl_iter_kernel<2>"),
-           ("rfx_stft.hip", "_ZN3rfx16stft_mel2_kernelILj2031647EEEvNS_11StftMelArgsE", "rfx::stft_mel2_kernel<0x1F001F>"),
+           ("rfx_stft.hip", "_ZN3rfx16stft_mel2_kernelILj2031647ELb1EEEvNS_11StftMelArgsE", "rfx::stft_mel2_kernel<0x1F001F>"),
            # one trip = one SGD step of one frame (one wave); its 16 DPP wave shifts count as plain here (measured 2.1 ns each)
            ("rfx_imel.hip", "_ZN3rfx16imel_wave_kernelILb1EEEvNS_8ImelArgsE", "rfx::imel_wave_kernel")]
 TRANS = {"v_rsq_f32_e32", "v_rcp_f32_e32", "v_sqrt_f32_e32", "v_rsq_f32_e64", "v_rcp_f32_e64", "v_sqrt_f32_e64"}
