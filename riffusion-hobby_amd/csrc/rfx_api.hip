@@ -757,7 +757,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
       const size_t o_w = take(nnz * 4), o_ptr = take((M + 1) * 4), o_lo = take(M * 4), o_m0 = take(F * 4),
                    o_w0 = take(F * 4), o_w1 = take(F * 4), o_p = take(F * 4), o_p2 = take(F * 4),
-                   o_gs = take((M + 1) * 4), o_lin = take(4 * (size_t)M * 4);
+                   o_gs = take((M + 1) * 4), o_lin = take(4 * (size_t)M * 4), o_pb = take((size_t)pl->frame_stride * 4);
       std::vector<char> blob(off);
       memcpy(&blob[o_w], csr_w.data(), nnz * 4);
       memcpy(&blob[o_ptr], csr_ptr.data(), (M + 1) * 4);
@@ -768,6 +768,14 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       memcpy(&blob[o_p], bin_pos.data(), F * 4);
       memcpy(&blob[o_p2], bin_pos2.data(), F * 4);
       memcpy(&blob[o_gs], grp_start.data(), (M + 1) * 4);
+      {  // output position -> bin (a bin with two slots appears at both; padding positions hold zeros)
+        std::vector<int> pos_bin((size_t)pl->frame_stride, -1);
+        for (int f = 0; f < F; ++f) {
+          if (bin_pos[f] >= 0) pos_bin[bin_pos[f]] = f;
+          if (bin_pos2[f] >= 0) pos_bin[bin_pos2[f]] = f;
+        }
+        memcpy(&blob[o_pb], pos_bin.data(), pos_bin.size() * 4);
+      }
       if (fast && lin.size() == 4 * (size_t)M) memcpy(&blob[o_lin], lin.data(), 4 * (size_t)M * 4);
       RFX_HIP(hipMalloc(&pl->d_imel_blob, off));
       RFX_HIP(hipMemcpy(pl->d_imel_blob, blob.data(), off, hipMemcpyHostToDevice));
@@ -780,6 +788,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       pl->imel.bin_w1 = (const float*)(d + o_w1);
       pl->imel.bin_pos = (const int*)(d + o_p);
       pl->imel.bin_pos2 = (const int*)(d + o_p2);
+      pl->imel.pos_bin = (const int*)(d + o_pb);
       pl->imel.grp_start = (const int*)(d + o_gs);
       pl->imel.fast_ok = fast ? fast_code : 0;
       pl->imel.unit_form = fast && unit_form ? 1 : 0;

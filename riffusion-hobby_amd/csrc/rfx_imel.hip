@@ -672,18 +672,13 @@ __device__ __forceinline__ void wv_update(WvChunk<NP, NF, UF>& k, float vx, floa
 #pragma unroll
   for (int p = 0; p < NP; ++p) k.spec[p] = p < NF ? pk_add_clamp(k.spec[p], v[p]) : pk_fma_clamp(k.spec[p], v[p], k.mask[p < NF ? 0 : p - NF]);
 }
+// the chunk's bins, unscaled, into the frame's LDS stage (bin order: entry f - f_lo)
 template <int NP, int NF, bool UF>
-__device__ __forceinline__ void wv_store(const WvChunk<NP, NF, UF>& k, int g, const ImelTables& tb, float* out) {
+__device__ __forceinline__ void wv_stage(const WvChunk<NP, NF, UF>& k, int g, const ImelTables& tb, float* stage) {
   const int f0 = tb.grp_start[g], n = tb.grp_start[g + 1] - f0;
 #pragma unroll
   for (int i = 0; i < 2 * NP; ++i)
-    if (i < n) {
-      const int f = f0 + i;
-      const float v = kImelUnscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
-      out[tb.bin_pos[f]] = v;
-      const int p2 = tb.bin_pos2[f];
-      if (p2 >= 0) out[p2] = v;
-    }
+    if (i < n) stage[f0 + i - tb.f_lo] = kImelUnscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -986,24 +981,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #undef RFX_WV_UPDATE
   }
 
+  // The frame leaves in POSITION order, 16 bytes per lane, whole lines per wave-wide store (round 5).  The first version stored bin by
+  // bin: 9408 four-byte stores per frame to positions 336 B apart, 64 cache lines per wave-wide store - alone (max_iter = 1) the
+  // kernel took 2.05 ms per 64 tiles for 1.23 GB, and 1.2 ms of it stayed exposed behind the 200 steps (profiles/r05_imel_epilogue.txt).
+  // Now the wave parks its active bins in LDS in bin order, then walks the frame's positions: pos_bin says which bin a position
+  // holds - from the stage if a filter reaches it, its initial value (passed through bit for bit) if none does, zero for padding.
   float* out = a.out_slots + (size_t)frame * a.out_stride;
-#define RFX_WV_STORE(c) wv_store(k##c, imel_wave_group(c, lane), tb, out);
-  RFX_WV_CHUNKS(RFX_WV_STORE)
-#undef RFX_WV_STORE
-  for (int f = lane; f < a.n_stft; f += 64) {  // bins outside every filter pass their initial value through
-    if (f >= tb.f_lo && f < tb.f_hi) continue;
-    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f);
-    out[tb.bin_pos[f]] = v;
-    const int p2 = tb.bin_pos2[f];
-    if (p2 >= 0) out[p2] = v;
-  }
-  if (a.plain) {  // generic engine: bin-ordered rows, zero the tail of the frame stride
-    for (int p = a.n_stft + lane; p < a.out_stride; p += 64) out[p] = 0.f;
-  } else {
-    for (int p = lane; p < kFrameStride; p += 64) {
-      int q, kb;
-      if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
+  float* stage = part + a.max_iter;  // [f_hi - f_lo]
+#define RFX_WV_STAGE(c) wv_stage(k##c, imel_wave_group(c, lane), tb, stage);
+  RFX_WV_CHUNKS(RFX_WV_STAGE)
+#undef RFX_WV_STAGE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // one wave: its LDS operations execute in order, the compiler must keep them so
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto value_at = [&](int bin) {
+    if (bin < 0) return 0.f;
+    if (bin >= tb.f_lo && bin < tb.f_hi) return stage[bin - tb.f_lo];
+    return a.spec0 ? a.spec0[(size_t)frame * a.n_stft + bin] : rand_unit(rbase, bin);
+  };
+  if ((a.out_stride & 3) == 0) {
+    const int4* __restrict__ pb4 = reinterpret_cast<const int4*>(tb.pos_bin);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    for (int p4 = lane; p4 < (a.out_stride >> 2); p4 += 64) {
+      const int4 b = pb4[p4];
+      out4[p4] = float4{value_at(b.x), value_at(b.y), value_at(b.z), value_at(b.w)};
     }
+  } else {
+    for (int p = lane; p < a.out_stride; p += 64) out[p] = value_at(tb.pos_bin[p]);
   }
   if (a.loss_hist && !a.it_limit) {
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS atomics
@@ -1073,8 +1077,9 @@ static void launch_perwave(const ImelArgs& a, hipStream_t stream) {
 hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
 #if RFX_IMEL_PK && RFX_IMEL_WAVE
   if (a.tb.wave_ok && variant == 0) {  // one wave per frame (the fix-up pass too: its frames are independent of each other)
-    if (a.tb.unit_form) hipLaunchKernelGGL(imel_wave_kernel<true>, dim3(a.B * a.T), dim3(64), sizeof(float) * (size_t)a.max_iter, stream, a);
-    else hipLaunchKernelGGL(imel_wave_kernel<false>, dim3(a.B * a.T), dim3(64), sizeof(float) * (size_t)a.max_iter, stream, a);
+    const size_t lds = sizeof(float) * ((size_t)a.max_iter + (size_t)(a.tb.f_hi - a.tb.f_lo));  // loss words + the epilogue's stage (16.8 KB: eight waves per CU)
+    if (a.tb.unit_form) hipLaunchKernelGGL(imel_wave_kernel<true>, dim3(a.B * a.T), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL(imel_wave_kernel<false>, dim3(a.B * a.T), dim3(64), lds, stream, a);
     return hipGetLastError();
   }
 #endif

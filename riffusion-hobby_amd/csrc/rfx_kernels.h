@@ -178,6 +178,7 @@ struct ImelTables {
   const float* bin_w1;   // [n_stft] weight into mel m0+1 (0 if none)
   const int* bin_pos;    // [n_stft] slot position of the bin's primary slot
   const int* bin_pos2;   // [n_stft] slot position of its duplicate slot, or -1
+  const int* pos_bin;    // [frame stride] the inverse map: bin held by output position p, -1 for the padding (round 5: the wave kernel's staged epilogue)
   const int* grp_start;  // [M+1] first bin of group g (bins whose first filter is g), fast path only
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
   int nnz;
