@@ -207,6 +207,34 @@ __device__ __forceinline__ float wave_sum(float x) {
 // at m = -1 and m = M, a dump entry for absent groups at m = M + 1 and its right neighbour), per-wave partial losses
 // [max_iter][4]
 RFX_HD size_t imel_group_lds_bytes(int M, int max_iter) { return sizeof(float) * (size_t)(4 * (M + 4) + 4 * max_iter); }
+// ... followed by the epilogue's stage: the frame's active bins in bin order (round 5, see imel_emit_frame)
+RFX_HD size_t imel_frame_lds_bytes(int M, int max_iter, int band) { return imel_group_lds_bytes(M, max_iter) + sizeof(float) * (size_t)((band + 3) & ~3); }
+
+// The frame leaves in POSITION order, 16 bytes per lane, whole lines per wave-wide store (round 5).  Until then every kernel
+// stored bin by bin: 9408 four-byte stores per frame to slot positions 336 B apart, 64 cache lines per wave-wide store - alone
+// (max_iter = 1) the wave kernel took 2.05 ms per 64 tiles for 1.23 GB, and 1.2 ms of it stayed exposed behind the 200 steps
+// (profiles/r05_imel_epilogue.txt).  Now the threads park the active bins in LDS in bin order (`stage`, entry f - f_lo; the caller
+// synchronises between the two halves), then walk the frame's positions: pos_bin says which bin a position holds - from the stage
+// if a filter reaches it, its initial value (passed through bit for bit) if none does, zero for padding.
+__device__ __forceinline__ void imel_emit_frame(const ImelArgs& a, const float* stage, int frame, unsigned rbase, int tid, int nthr) {
+  const ImelTables& tb = a.tb;
+  float* out = a.out_slots + (size_t)frame * a.out_stride;
+  auto value_at = [&](int bin) {
+    if (bin < 0) return 0.f;
+    if (bin >= tb.f_lo && bin < tb.f_hi) return stage[bin - tb.f_lo];
+    return a.spec0 ? a.spec0[(size_t)frame * a.n_stft + bin] : rand_unit(rbase, bin);
+  };
+  if ((a.out_stride & 3) == 0) {
+    const int4* __restrict__ pb4 = reinterpret_cast<const int4*>(tb.pos_bin);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    for (int p4 = tid; p4 < (a.out_stride >> 2); p4 += nthr) {
+      const int4 b = pb4[p4];
+      out4[p4] = float4{value_at(b.x), value_at(b.y), value_at(b.z), value_at(b.w)};
+    }
+  } else {
+    for (int p = tid; p < a.out_stride; p += nthr) out[p] = value_at(tb.pos_bin[p]);
+  }
+}
 
 // Two things keep the per-bin cost of a step at five instructions for the long groups (seven in round 2):
 //  * scaled state: spec, buf and the mel targets are held multiplied by kImelScale = 2^-60.  Every operation of the step
@@ -316,16 +344,10 @@ __device__ __forceinline__ void group_step(GroupState<N, UF>& g, float d0, float
   for (int i = 0; i < g.NP; ++i) g.spec[i] = pk_step_clamp(g.spec[i], nl2, g.buf[i]);
 }
 template <int N, bool UF>
-__device__ __forceinline__ void group_store(const GroupState<N, UF>& g, const ImelTables& tb, float* out, float unscale) {
+__device__ __forceinline__ void group_stage(const GroupState<N, UF>& g, const ImelTables& tb, float* stage, float unscale) {
 #pragma unroll
   for (int i = 0; i < 2 * g.NP; ++i)
-    if (i < g.n) {
-      const int f = g.f0 + i;
-      const float v = unscale * ((i & 1) ? g.spec[i >> 1].y : g.spec[i >> 1].x);
-      out[tb.bin_pos[f]] = v;
-      const int p2 = tb.bin_pos2[f];
-      if (p2 >= 0) out[p2] = v;
-    }
+    if (i < g.n) stage[g.f0 + i - tb.f_lo] = unscale * ((i & 1) ? g.spec[i >> 1].y : g.spec[i >> 1].x);
 }
 #else
 template <int N, bool UF>
@@ -387,16 +409,10 @@ __device__ __forceinline__ void group_step(GroupState<N, UF>& g, float d0, float
   }
 }
 template <int N, bool UF>
-__device__ __forceinline__ void group_store(const GroupState<N, UF>& g, const ImelTables& tb, float* out, float unscale) {
+__device__ __forceinline__ void group_stage(const GroupState<N, UF>& g, const ImelTables& tb, float* stage, float unscale) {
 #pragma unroll
   for (int i = 0; i < N; ++i)
-    if (i < g.n) {
-      const int f = g.f0 + i;
-      const float v = unscale * g.spec[i];
-      out[tb.bin_pos[f]] = v;
-      const int p2 = tb.bin_pos2[f];
-      if (p2 >= 0) out[p2] = v;
-    }
+    if (i < g.n) stage[g.f0 + i - tb.f_lo] = unscale * g.spec[i];
 }
 
 #endif
@@ -480,25 +496,12 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
   if (it < steps) sgd_step(it, A0, B0);
   __syncthreads();
 
+  float* stage = reinterpret_cast<float*>(smem + imel_group_lds_bytes(M, a.max_iter));  // behind the loss partials (imel_frame_lds_bytes)
+  group_stage(lo, tb, stage, kUnscale);
+  group_stage(hi, tb, stage, kUnscale);
+  __syncthreads();  // (every frame of the workgroup: a slot without a frame computes a copy of the last one and stores nothing)
   if (!live) return;
-  float* out = a.out_slots + (size_t)frame * a.out_stride;
-  group_store(lo, tb, out, kUnscale);
-  group_store(hi, tb, out, kUnscale);
-  for (int f = tid; f < a.n_stft; f += kImelThreads) {
-    if (f >= tb.f_lo && f < tb.f_hi) continue;
-    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f);
-    out[tb.bin_pos[f]] = v;
-    const int p2 = tb.bin_pos2[f];
-    if (p2 >= 0) out[p2] = v;
-  }
-  if (a.plain) {  // generic engine: bin-ordered rows, zero the tail of the frame stride
-    for (int p = a.n_stft + tid; p < a.out_stride; p += kImelThreads) out[p] = 0.f;
-  } else {
-    for (int p = tid; p < kFrameStride; p += kImelThreads) {
-      int q, kb;
-      if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
-    }
-  }
+  imel_emit_frame(a, stage, frame, rbase, tid, kImelThreads);
   if (a.loss_hist && !a.it_limit)
     for (int i = tid; i < a.max_iter; i += kImelThreads)
       a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]) : 0.f;
@@ -544,7 +547,7 @@ imel_group_kernel_perwave(ImelArgs a) {
   int frame = blockIdx.x * FPW + slot;
   const bool live = frame < nframes;
   if (!live) frame = nframes - 1;
-  char* my = smem + (size_t)slot * imel_group_lds_bytes(a.M, a.max_iter);
+  char* my = smem + (size_t)slot * imel_frame_lds_bytes(a.M, a.max_iter, a.tb.f_hi - a.tb.f_lo);
   switch (cls) {
     case 0: imel_group_body<L0, H0, UF>(a, my, tid, frame, live); break;
     case 1: imel_group_body<L1, H1, UF>(a, my, tid, frame, live); break;
@@ -757,18 +760,12 @@ __device__ __forceinline__ void line_step(LineGroup<NP, UF>& k, float n0, float 
   }
 }
 template <int NP, bool UF>
-__device__ __forceinline__ void line_store(const LineGroup<NP, UF>& k, int g, const ImelTables& tb, float* out) {
+__device__ __forceinline__ void line_stage(const LineGroup<NP, UF>& k, int g, const ImelTables& tb, float* stage) {
   if (g < 0) return;
   const int f0 = tb.grp_start[g], n = tb.grp_start[g + 1] - f0;
 #pragma unroll
   for (int i = 0; i < 2 * NP; ++i)
-    if (i < n) {
-      const int f = f0 + i;
-      const float v = kImelUnscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
-      out[tb.bin_pos[f]] = v;
-      const int p2 = tb.bin_pos2[f];
-      if (p2 >= 0) out[p2] = v;
-    }
+    if (i < n) stage[f0 + i - tb.f_lo] = kImelUnscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
 }
 
 // the group body (imel_group_body) with the long group in line form; same roles, same LDS layout, same barriers
@@ -834,24 +831,11 @@ __device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, in
   if (it < steps) sgd_step(it, A0, B0);
   __syncthreads();
 
-  float* out = a.out_slots + (size_t)frame * a.out_stride;
-  group_store(lo, tb, out, kImelUnscale);
-  line_store(hi, gH, tb, out);
-  for (int f = tid; f < a.n_stft; f += kImelThreads) {
-    if (f >= tb.f_lo && f < tb.f_hi) continue;
-    const float v = a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f);
-    out[tb.bin_pos[f]] = v;
-    const int p2 = tb.bin_pos2[f];
-    if (p2 >= 0) out[p2] = v;
-  }
-  if (a.plain) {
-    for (int p = a.n_stft + tid; p < a.out_stride; p += kImelThreads) out[p] = 0.f;
-  } else {
-    for (int p = tid; p < kFrameStride; p += kImelThreads) {
-      int q, kb;
-      if (!pos_f_to_slot(p, q, kb)) out[p] = 0.f;
-    }
-  }
+  float* stage = reinterpret_cast<float*>(smem + imel_group_lds_bytes(M, a.max_iter));
+  group_stage(lo, tb, stage, kImelUnscale);
+  line_stage(hi, gH, tb, stage);
+  __syncthreads();
+  imel_emit_frame(a, stage, frame, rbase, tid, kImelThreads);
   if (a.loss_hist && !a.it_limit)
     for (int i = tid; i < a.max_iter; i += kImelThreads)
       a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]) : 0.f;
@@ -981,12 +965,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #undef RFX_WV_UPDATE
   }
 
-  // The frame leaves in POSITION order, 16 bytes per lane, whole lines per wave-wide store (round 5).  The first version stored bin by
-  // bin: 9408 four-byte stores per frame to positions 336 B apart, 64 cache lines per wave-wide store - alone (max_iter = 1) the
-  // kernel took 2.05 ms per 64 tiles for 1.23 GB, and 1.2 ms of it stayed exposed behind the 200 steps (profiles/r05_imel_epilogue.txt).
-  // Now the wave parks its active bins in LDS in bin order, then walks the frame's positions: pos_bin says which bin a position
-  // holds - from the stage if a filter reaches it, its initial value (passed through bit for bit) if none does, zero for padding.
-  float* out = a.out_slots + (size_t)frame * a.out_stride;
+  // the frame leaves through the LDS stage (imel_emit_frame): active bins parked in bin order, then one walk over the positions
   float* stage = part + a.max_iter;  // [f_hi - f_lo]
 #define RFX_WV_STAGE(c) wv_stage(k##c, imel_wave_group(c, lane), tb, stage);
   RFX_WV_CHUNKS(RFX_WV_STAGE)
@@ -994,21 +973,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // one wave: its LDS operations execute in order, the compiler must keep them so
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  auto value_at = [&](int bin) {
-    if (bin < 0) return 0.f;
-    if (bin >= tb.f_lo && bin < tb.f_hi) return stage[bin - tb.f_lo];
-    return a.spec0 ? a.spec0[(size_t)frame * a.n_stft + bin] : rand_unit(rbase, bin);
-  };
-  if ((a.out_stride & 3) == 0) {
-    const int4* __restrict__ pb4 = reinterpret_cast<const int4*>(tb.pos_bin);
-    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
-    for (int p4 = lane; p4 < (a.out_stride >> 2); p4 += 64) {
-      const int4 b = pb4[p4];
-      out4[p4] = float4{value_at(b.x), value_at(b.y), value_at(b.z), value_at(b.w)};
-    }
-  } else {
-    for (int p = lane; p < a.out_stride; p += 64) out[p] = value_at(tb.pos_bin[p]);
-  }
+  imel_emit_frame(a, stage, frame, rbase, lane, 64);
   if (a.loss_hist && !a.it_limit) {
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS atomics
     for (int i = lane; i < a.max_iter; i += 64) a.loss_hist[(size_t)frame * a.max_iter + i] = i < steps ? part[i] : 0.f;
@@ -1065,7 +1030,7 @@ __global__ void __launch_bounds__(1024) imel_scan_kernel(const float* __restrict
 template <int FPW, int SET, bool UF>
 static void launch_perwave(const ImelArgs& a, hipStream_t stream) {
   const int nframes = a.B * a.T;
-  const size_t lds = FPW * imel_group_lds_bytes(a.M, a.max_iter);
+  const size_t lds = FPW * imel_frame_lds_bytes(a.M, a.max_iter, a.tb.f_hi - a.tb.f_lo);
   constexpr const int* lo = SET == 0 ? kImelLoCap : kImelLoCapWide;
   constexpr const int* hi = SET == 0 ? kImelHiCap : kImelHiCapWide;
   // the wide set's class 0 holds 31 bins per thread (124 state registers): three waves per SIMD (168 VGPRs) instead of four
@@ -1087,7 +1052,7 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
   if (a.tb.fast_ok == 5 && variant == 0) {  // long groups in line form (full-band banks, 384 filters ...)
     constexpr const int* lo = kImelLoCapLine;
     constexpr const int* hi = kImelHiCapLine;
-    const size_t lds = imel_group_lds_bytes(a.M, a.max_iter);
+    const size_t lds = imel_frame_lds_bytes(a.M, a.max_iter, a.tb.f_hi - a.tb.f_lo);
     if (a.tb.unit_form) hipLaunchKernelGGL((imel_line_kernel_perwave<true, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
     else hipLaunchKernelGGL((imel_line_kernel_perwave<false, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]>), dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
     return hipGetLastError();
@@ -1109,7 +1074,7 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
         if (fixup) launch_perwave<1, 1, false>(a, stream); else launch_perwave<RFX_IMEL_FPW, 1, false>(a, stream);
       }
     } else {
-      hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), imel_group_lds_bytes(a.M, a.max_iter), stream, a);
+      hipLaunchKernelGGL((imel_group_kernel<8, 24>), dim3(a.B * a.T), dim3(kImelThreads), imel_frame_lds_bytes(a.M, a.max_iter, a.tb.f_hi - a.tb.f_lo), stream, a);
     }
     return hipGetLastError();
   }
