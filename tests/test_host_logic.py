@@ -469,3 +469,18 @@ def test_c_abi_refuses_bad_plan_options_before_any_device_call(repo_root):
                       (_hip.RfxPlanOptions(size + 4, 0, 0, 0, 0, 0), b"struct_size"), (_hip.RfxPlanOptions(4, 0, 0, 0, 0, 0), b"struct_size")):
         rc = lib.rfx_plan_create_ex(ctypes.byref(cp), ctypes.cast(win, ctypes.c_void_p), None, 0, ctypes.byref(opt), ctypes.byref(handle))
         assert rc != 0 and not handle.value and word in lib.rfx_last_error(), (rc, lib.rfx_last_error())
+
+
+def test_c_abi_image_from_waveform_refuses_null_arguments_before_any_device_call():
+    """rfx_image_from_waveform (spectrogram_image_converter.py:30-51 in one call) checks its arguments first: a null plan / buffer is
+    RFX_ERR_INVALID with a message naming the entry point, and the workspace query answers 0 for a null plan - no GPU needed."""
+    import ctypes
+
+    from riffusion import _hip
+
+    lib = _hip.load_library()
+    assert lib.rfx_image_from_waveform_workspace_bytes(None, 4, 0, 44100) == 0
+    buf = (ctypes.c_float * 16)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.rfx_image_from_waveform(None, ptr, 1, 0, 44100, ptr, ptr, ptr, ptr, 1 << 20, None)
+    assert rc != 0 and b"rfx_image_from_waveform" in lib.rfx_last_error(), (rc, lib.rfx_last_error())
