@@ -1,5 +1,6 @@
 #!/bin/bash
-# Builds experiment variants of librfx.so into build_var/ (git-ignored; travels to the GPU box).
+# Builds experiment variants of librfx.so into build_var/ (git-ignored; travels to the GPU box).  (tools/build_variant_fast.sh does the same
+# for ONE variant and recompiles only the translation units the flags concern: 35 s instead of minutes.)
 #   tools/build_variants.sh name1:"-DFLAG ..." name2:"..."     (source dir override: SRC=/path/to/csrc)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
