@@ -221,6 +221,15 @@ size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T);
 int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                     uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- inverse, in one call: SpectrogramConverter.waveform_from_mel_amplitudes, spectrogram_converter.py:187-204
+ * (`self.inverse_mel_scaler(amplitudes_mel)` :201 then `self.inverse_spectrogram_func(amplitudes_linear)` :204).
+ * d_mel (B, n_mels, T) -> d_wave_out (B, rfx_griffinlim_output_samples(plan, T)); clips of `channels_per_clip` rows as in
+ * rfx_inverse_mel; both random starts from `seed` (the SGD start from seed, the phases from seed + 1).  Exactly rfx_inverse_mel
+ * followed by rfx_griffinlim - same bits - with the linear magnitudes kept inside the workspace. */
+size_t rfx_waveform_from_mel_workspace_bytes(const rfx_plan* plan, int B, int T);
+int rfx_waveform_from_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
+                          float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* ---- image codec: riffusion/util/image_util.py -----------------------------------------------
  * decode = spectrogram_from_image (:81-108): d_img (N, H, W, 3) uint8 RGB -> (N*C, H, W) float32,
  *   C = 2 (G,B planes) when stereo else 1 (R plane); d_lut256[p] is the float32 value numpy's chain

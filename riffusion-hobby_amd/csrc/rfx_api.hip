@@ -1519,6 +1519,30 @@ int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int 
   return RFX_OK;
 }
 
+// ---- SpectrogramConverter.waveform_from_mel_amplitudes in one call (spectrogram_converter.py:187-204: inverse_mel_scaler, then
+// inverse_spectrogram_func).  rfx_inverse_mel into the head of the workspace, rfx_griffinlim from there: the same two launches
+// sequences, the same seeds (seed for the SGD start, seed + 1 for the phases, as the Python layer always called them), the linear
+// magnitudes never leave the library.
+size_t rfx_waveform_from_mel_workspace_bytes(const rfx_plan* plan, int B, int T) {
+  if (!plan || B <= 0 || T <= 0) return 0;
+  const size_t imel = rfx_inverse_mel_workspace_bytes(plan, B, T), gl = rfx_griffinlim_workspace_bytes(plan, B, T);
+  if (!imel || !gl) return 0;
+  return align_up((size_t)B * T * plan->frame_stride * sizeof(float), 256) + (imel > gl ? imel : gl);
+}
+
+int rfx_waveform_from_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
+                          float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!plan || !d_mel || !d_wave_out || !d_workspace || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_waveform_from_mel: bad argument");
+  const size_t need = rfx_waveform_from_mel_workspace_bytes(plan, B, T);
+  if (!need) return fail(RFX_ERR_UNSUPPORTED, "rfx_waveform_from_mel: this plan cannot invert (see rfx_inverse_mel / rfx_griffinlim)");
+  if (workspace_bytes < need) return fail(RFX_ERR_WORKSPACE, "rfx_waveform_from_mel: workspace too small");
+  float* lin = reinterpret_cast<float*>(d_workspace);
+  const size_t lin_bytes = align_up((size_t)B * T * plan->frame_stride * sizeof(float), 256);
+  void* rest = (char*)d_workspace + lin_bytes;
+  if (int rc = rfx_inverse_mel(plan, d_mel, B, T, channels_per_clip, nullptr, seed, lin, rest, workspace_bytes - lin_bytes, stream)) return rc;
+  return rfx_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, stream);
+}
+
 int rfx_image_decode_u8(const uint8_t* d_img, int N, int H, int W, int stereo, const float* d_lut256, float* d_mel_out,
                         void* stream) {
   if (!d_img || !d_lut256 || !d_mel_out || N <= 0 || H <= 0 || W <= 0) return fail(RFX_ERR_INVALID, "rfx_image_decode_u8: bad argument");

@@ -107,6 +107,8 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     ),
     "rfx_image_decode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rfx_image_encode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rfx_waveform_from_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "rfx_waveform_from_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_uint64, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rfx_image_from_waveform_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "rfx_image_from_waveform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rfx_pcm16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -483,6 +485,19 @@ class Plan:
         mx = torch.empty((N,), dtype=torch.float32, device=mel.device)
         check(self.lib.rfx_image_encode_u8(mel.data_ptr(), N, M, Tn, int(stereo), thresholds.data_ptr(), mx.data_ptr(), img.data_ptr(), self._stream()))
         return img, mx
+
+    def waveform_from_mel(self, mel: torch.Tensor, channels_per_clip: int, n_iter: int, momentum: float = 0.99, seed: int = 0) -> torch.Tensor:
+        """spectrogram_converter.py:187-204 in one call: (B, n_mels, T) -> (B, hop * (T - 1)); `inverse_mel` (seed) + `griffinlim`
+        (seed + 1), same bits, the linear magnitudes stay in the workspace."""
+        mel = self._chk(mel, torch.float32)
+        B, M, Tn = mel.shape
+        if M != self.n_mels:
+            raise ValueError(f"Expected an input with {self.n_mels} mel bins. Found: {M}")  # torchaudio's message
+        ws = torch.empty(self.lib.rfx_waveform_from_mel_workspace_bytes(self.handle, B, Tn), dtype=torch.uint8, device=mel.device)
+        out = torch.empty((B, self.lib.rfx_griffinlim_output_samples(self.handle, Tn)), dtype=torch.float32, device=mel.device)
+        check(self.lib.rfx_waveform_from_mel(self.handle, mel.data_ptr(), B, Tn, channels_per_clip, seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
+                                             out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        return out
 
     def image_from_waveform(self, wave: torch.Tensor, stereo: bool, thresholds: torch.Tensor):
         """spectrogram_image_converter.py:30-51 on the device: (N*C, Lw) float32 -> ((N, n_mels, T, 3) uint8, per-clip max (N,));

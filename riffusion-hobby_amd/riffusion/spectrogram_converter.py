@@ -175,6 +175,8 @@ class SpectrogramConverter:
         B, _, Tn = mel.shape
         cpc = B if channels_per_clip is None else channels_per_clip
         s = self._seed(seed)
+        if spec0 is None and angles0 is None:  # the production path: one call (rfx_waveform_from_mel), same bits as the two below
+            return plan.waveform_from_mel(mel, cpc, self.p.num_griffin_lim_iters, 0.99, seed=s)
         spec0 = spec0.to(self.device) if spec0 is not None else None
         lin_slots = plan.inverse_mel(mel, cpc, spec0=spec0, seed=s)
         a0 = plan.pack_complex(angles0.to(self.device)) if angles0 is not None else None

@@ -181,3 +181,23 @@ def test_forward_kernel_with_packed_tables_against_the_dense_definition(plan):
         worst = float(((mel.double() - ref_mel).abs() / (ref_mel.abs() + 1e-3 * ref_mel.abs().max())).max())
         print(f"forward kernel, B = {B}, T = {Tn}: rel-L2 {rel:.2e} against the float64 dense definition, worst relative entry {worst:.2e}")
         assert rel < 5e-7 and worst < 1e-4
+
+
+@pytest.mark.parametrize("kw,B,cpc,Tn", [({}, 4, 2, 96), ({}, 1, 1, 24), ({"sample_rate": 48000, "max_frequency": 10000}, 2, 1, 40),
+                                         ({"sample_rate": 11025, "max_frequency": 5000}, 2, 2, 30)])
+def test_waveform_from_mel_equals_the_two_calls_bit_for_bit(kw, B, cpc, Tn):
+    """spectrogram_converter.py:187-204.  rfx_waveform_from_mel keeps the linear magnitudes inside its workspace; what comes out must be
+    rfx_inverse_mel (seed) followed by rfx_griffinlim (seed + 1), to the bit, on every engine."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    p = SpectrogramParams(num_griffin_lim_iters=5, **kw)
+    plan = _hip.get_plan(p, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(9 + Tn)
+    mel = torch.rand(B, p.num_frequencies, Tn, device="cuda", generator=g) ** 3 * 2e6
+    lin = plan.inverse_mel(mel, cpc, seed=1234)
+    two = plan.griffinlim(lin, B, Tn, 5, 0.99, seed=1235)
+    one = plan.waveform_from_mel(mel, cpc, 5, 0.99, seed=1234)
+    assert one.shape == two.shape == (B, p.hop_length * (Tn - 1)) and bool(torch.isfinite(one).all())
+    assert torch.equal(one.view(torch.int32), two.view(torch.int32))
+    assert float(one.abs().max()) > 0

@@ -484,3 +484,17 @@ def test_c_abi_image_from_waveform_refuses_null_arguments_before_any_device_call
     ptr = ctypes.cast(buf, ctypes.c_void_p)
     rc = lib.rfx_image_from_waveform(None, ptr, 1, 0, 44100, ptr, ptr, ptr, ptr, 1 << 20, None)
     assert rc != 0 and b"rfx_image_from_waveform" in lib.rfx_last_error(), (rc, lib.rfx_last_error())
+
+
+def test_c_abi_waveform_from_mel_refuses_null_arguments_before_any_device_call():
+    """rfx_waveform_from_mel (spectrogram_converter.py:187-204 in one call): a null plan is RFX_ERR_INVALID, the workspace query 0."""
+    import ctypes
+
+    from riffusion import _hip
+
+    lib = _hip.load_library()
+    assert lib.rfx_waveform_from_mel_workspace_bytes(None, 2, 64) == 0
+    buf = (ctypes.c_float * 16)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.rfx_waveform_from_mel(None, ptr, 1, 64, 1, 0, 4, ctypes.c_float(0.99), ptr, ptr, 1 << 20, None)
+    assert rc != 0 and b"rfx_waveform_from_mel" in lib.rfx_last_error(), (rc, lib.rfx_last_error())
