@@ -64,11 +64,11 @@ def scatter_instructions(f_lo, f_hi, m0):
     return out
 
 
-def write_cycles(instrs, pos, dump0):
+def write_cycles(instrs, pos, dump0=0):
     """LDS-array cycles of the scatter per frame (one array; the second array shifts every address by `arr`)."""
     total, ideal = 0, 0
     for w, kb, lanes in instrs:
-        addr = {lane: dump0 + w * 64 + lane for lane in range(63)}  # non-contributing lanes: their dump float
+        addr = {lane: dump0 + w * 64 + lane for lane in range(63)}  # non-contributing lanes: their dump float ([0, 448) since round 5)
         for lane, b in lanes:
             addr[lane] = pos[b]
         for grp in (range(0, 32), range(32, 63)):
@@ -110,7 +110,7 @@ def positions(G, gfirst, cnt):
 
 
 def dense_placement(cnt):
-    G = np.concatenate([[0], np.cumsum((cnt + 3) // 4 * 4)])
+    G = KQ + np.concatenate([[0], np.cumsum((cnt + 3) // 4 * 4)])  # the groups follow the dump floats (rfx_api.hip: G[0] = kQPad)
     return G[:-1], int(G[-1])
 
 
@@ -134,7 +134,7 @@ def searched_placement(cnt, gfirst, instrs, budget, seed=0, sweeps=6):
         G, arr = build(gaps)
         if arr > budget:
             return 1 << 30
-        return write_cycles(instrs, positions(G, gfirst, cnt), 2 * arr)[0]
+        return write_cycles(instrs, positions(G, gfirst, cnt))[0]
 
     best = cost(gaps)
     rng = np.random.default_rng(seed)
@@ -166,7 +166,7 @@ if __name__ == "__main__":
     instrs = scatter_instructions(f_lo, f_hi, m0)
     G, arr = dense_placement(cnt)
     pos = positions(G, gfirst, cnt)
-    w, wi = write_cycles(instrs, pos, 2 * arr)
+    w, wi = write_cycles(instrs, pos)
     r, ri = read_cycles(G, cnt, arr, len(cnt))
     print(f"bins {f_lo}..{f_hi}, groups {len(cnt)} (longest {cnt.max()}), store instructions with work: {len(instrs)}")
-    print(f"dense placement: arr {arr} floats; scatter {w} cycles (conflict-free {wi}); segment reads {r} (conflict-free {ri})")
+    print(f"dense placement: first array ends at {arr} floats; scatter {w} cycles (conflict-free {wi}); segment reads {r} (conflict-free {ri})")
