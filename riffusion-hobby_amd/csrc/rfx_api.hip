@@ -994,9 +994,11 @@ static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames
   total = o;
 }
 
+// mag_in_fam_slots (rfx_waveform_from_mel on a row-family plan): d_mag already holds the family kernels' slot order [B*T][fsf] -
+// InverseMelScale wrote it that way - so the once-per-call re-ordering of the plain frames is left out
 static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* d_angles0, uint64_t seed, int B, int T, int n_iter,
                           float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream,
-                          float* h_launch_ms) {
+                          float* h_launch_ms, bool mag_in_fam_slots = false) {
   const GenGeom& g = plan->gg;
   const int L = gen_out_len(g, T);
   if (n_iter > 0 && L <= g.n_fft / 2)
@@ -1021,8 +1023,12 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   }
   if (plan->fam_ok) {
     const FamGeom& f = plan->fam;
-    float* S_slots = (float*)(ws + oa + align_up((3 * (size_t)B + 1) * Lpad * sizeof(float), 256));
-    RFX_HIP(launch_fam_repack(d_mag, S_slots, plan->d_fam_binof, (long long)B * T, g.fs, f.fsf, f.n_stft, stream));
+    const float* S_slots = d_mag;
+    if (!mag_in_fam_slots) {
+      float* repacked = (float*)(ws + oa + align_up((3 * (size_t)B + 1) * Lpad * sizeof(float), 256));
+      RFX_HIP(launch_fam_repack(d_mag, repacked, plan->d_fam_binof, (long long)B * T, g.fs, f.fsf, f.n_stft, stream));
+      S_slots = repacked;
+    }
     FamGlArgs fa{};
     fa.g = f;
     fa.S = S_slots;
@@ -1475,8 +1481,22 @@ size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T) {
   return align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256) + align_up((size_t)(B + 1) * sizeof(int), 256);
 }
 
+// can InverseMelScale write a row-family plan's frames straight in the family kernels' slot order?  (Every kernel that leaves
+// through imel_emit_frame can: the output order is just its pos_bin table.  The general LDS kernel stores bin by bin.)
+static bool imel_can_emit_fam_slots(const rfx_plan* plan) {
+  return plan->generic && plan->fam_ok && plan->imel_ok && plan->d_fam_binof && (plan->imel.wave_ok || plan->imel.fast_ok) && plan->imel_variant == 0;
+}
+
+static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
+                            uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots);
+
 int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                     uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_) {
+  return inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, d_spec0, seed, d_mag_slots, d_workspace, workspace_bytes, stream_, false);
+}
+
+static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
+                            uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots) {
   if (!plan || !d_mel || !d_mag_slots || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: null argument");
   if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: plan was created without a mel filterbank");
   if (!plan->imel_ok) return fail(RFX_ERR_UNSUPPORTED, "rfx_inverse_mel: filterbank is not banded: " + plan->imel_why);
@@ -1505,6 +1525,10 @@ int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int 
   a.n_stft = plan->n_stft;
   a.out_stride = plan->frame_stride;
   a.plain = plan->generic ? 1 : 0;
+  if (fam_slots) {  // (imel_can_emit_fam_slots: the frame's positions are the family kernels' slots)
+    a.tb.pos_bin = plan->d_fam_binof;
+    a.out_stride = plan->fam.fsf;
+  }
   a.max_iter = plan->p.max_mel_iters;
   a.lr = 0.1f;        // sgdargs=None -> {"lr": 0.1, "momentum": 0.9} (torchaudio 0.13 InverseMelScale)
   a.momentum = 0.9f;
@@ -1527,7 +1551,8 @@ size_t rfx_waveform_from_mel_workspace_bytes(const rfx_plan* plan, int B, int T)
   if (!plan || B <= 0 || T <= 0) return 0;
   const size_t imel = rfx_inverse_mel_workspace_bytes(plan, B, T), gl = rfx_griffinlim_workspace_bytes(plan, B, T);
   if (!imel || !gl) return 0;
-  return align_up((size_t)B * T * plan->frame_stride * sizeof(float), 256) + (imel > gl ? imel : gl);
+  const size_t stride = imel_can_emit_fam_slots(plan) ? (size_t)plan->fam.fsf : (size_t)plan->frame_stride;
+  return align_up((size_t)B * T * stride * sizeof(float), 256) + (imel > gl ? imel : gl);
 }
 
 int rfx_waveform_from_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
@@ -1537,10 +1562,16 @@ int rfx_waveform_from_mel(const rfx_plan* plan, const float* d_mel, int B, int T
   if (!need) return fail(RFX_ERR_UNSUPPORTED, "rfx_waveform_from_mel: this plan cannot invert (see rfx_inverse_mel / rfx_griffinlim)");
   if (workspace_bytes < need) return fail(RFX_ERR_WORKSPACE, "rfx_waveform_from_mel: workspace too small");
   float* lin = reinterpret_cast<float*>(d_workspace);
-  const size_t lin_bytes = align_up((size_t)B * T * plan->frame_stride * sizeof(float), 256);
+  // a row-family plan's magnitudes go from the SGD kernel to the Griffin-Lim kernels in THEIR slot order: the once-per-call
+  // re-ordering of plain frames (0.75 ms and 2.5 GB of traffic per 64 tiles at 48 kHz) exists only for callers of the two entry points
+  const bool fam_slots = imel_can_emit_fam_slots(plan);
+  const size_t lin_bytes = align_up((size_t)B * T * (fam_slots ? (size_t)plan->fam.fsf : (size_t)plan->frame_stride) * sizeof(float), 256);
   void* rest = (char*)d_workspace + lin_bytes;
-  if (int rc = rfx_inverse_mel(plan, d_mel, B, T, channels_per_clip, nullptr, seed, lin, rest, workspace_bytes - lin_bytes, stream)) return rc;
-  return rfx_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, stream);
+  if (int rc = inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, nullptr, seed, lin, rest, workspace_bytes - lin_bytes, stream, fam_slots)) return rc;
+  if (!fam_slots) return rfx_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, stream);
+  if (T < 2 || n_iter < 0 || (long long)B * T > 0x7fffffffLL || !(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_waveform_from_mel: bad shape");
+  RFX_ON_DEVICE(plan->device);
+  return gen_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, (hipStream_t)stream, nullptr, true);
 }
 
 int rfx_image_decode_u8(const uint8_t* d_img, int N, int H, int W, int stereo, const float* d_lut256, float* d_mel_out,
