@@ -248,6 +248,17 @@ int rfx_image_encode_u8(const float* d_mel, int N, int M, int T, int stereo, con
  * zero.  d_clip_peak (N floats) receives max|x| per clip. */
 int rfx_pcm16(const float* d_wave, int N, int C, int L, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* stream);
 
+/* ---- inverse, all the way from the image: SpectrogramImageConverter.audio_from_spectrogram_image's device half
+ * (spectrogram_image_converter.py:54-91: image_util.spectrogram_from_image, audio_from_spectrogram -> waveform_from_mel_amplitudes
+ * on the image's (C, n_mels, T) tensor, audio_util.audio_from_waveform).  d_img (N, n_mels, T, 3) uint8 -> d_pcm_out (N, L, C) int16,
+ * L = rfx_griffinlim_output_samples(plan, T); d_clip_peak (N floats) as rfx_pcm16; d_lut256 as rfx_image_decode_u8.  Exactly
+ * rfx_image_decode_u8, rfx_waveform_from_mel (clips of C rows, `seed`), rfx_pcm16 - same bytes - with the tensors in between
+ * kept inside the workspace. */
+size_t rfx_audio_from_image_workspace_bytes(const rfx_plan* plan, int N, int stereo, int T);
+int rfx_audio_from_image_u8(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
+                            int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
+                            size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

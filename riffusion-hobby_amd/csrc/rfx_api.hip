@@ -1607,4 +1607,35 @@ int rfx_pcm16(const float* d_wave, int N, int C, int L, int normalize, float* d_
   return RFX_OK;
 }
 
+// ---- SpectrogramImageConverter.audio_from_spectrogram_image's device half in one call (spectrogram_image_converter.py:54-91:
+// image_util.spectrogram_from_image, SpectrogramConverter.audio_from_spectrogram -> waveform_from_mel_amplitudes on the image's
+// (C, n_mels, T) tensor, audio_util.audio_from_waveform): uint8 tiles in, int16 PCM out.  The three entry points it is made of,
+// in their order, with the same seeds: same bytes.
+size_t rfx_audio_from_image_workspace_bytes(const rfx_plan* plan, int N, int stereo, int T) {
+  if (!plan || N <= 0 || T <= 0) return 0;
+  const int C = stereo ? 2 : 1, B = N * C;
+  const size_t inner = rfx_waveform_from_mel_workspace_bytes(plan, B, T);
+  if (!inner) return 0;
+  return align_up((size_t)B * plan->p.n_mels * T * sizeof(float), 256) + align_up((size_t)B * rfx_griffinlim_output_samples(plan, T) * sizeof(float), 256) + inner;
+}
+
+int rfx_audio_from_image_u8(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
+                            int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!plan || !d_img || !d_lut256 || !d_clip_peak || !d_pcm_out || !d_workspace || N <= 0 || T <= 0)
+    return fail(RFX_ERR_INVALID, "rfx_audio_from_image_u8: bad argument");
+  const size_t need = rfx_audio_from_image_workspace_bytes(plan, N, stereo, T);
+  if (!need) return fail(RFX_ERR_UNSUPPORTED, "rfx_audio_from_image_u8: this plan cannot invert (see rfx_inverse_mel / rfx_griffinlim)");
+  if (workspace_bytes < need) return fail(RFX_ERR_WORKSPACE, "rfx_audio_from_image_u8: workspace too small");
+  const int C = stereo ? 2 : 1, B = N * C, M = plan->p.n_mels, L = rfx_griffinlim_output_samples(plan, T);
+  float* mel = reinterpret_cast<float*>(d_workspace);
+  const size_t mel_bytes = align_up((size_t)B * M * T * sizeof(float), 256), wave_bytes = align_up((size_t)B * L * sizeof(float), 256);
+  float* wave = reinterpret_cast<float*>((char*)d_workspace + mel_bytes);
+  void* rest = (char*)d_workspace + mel_bytes + wave_bytes;
+  if (int rc = rfx_image_decode_u8(d_img, N, M, T, stereo, d_lut256, mel, stream)) return rc;
+  // (a clip is one image: its channels share the SGD loss mean and the peak normalisation)
+  if (int rc = rfx_waveform_from_mel(plan, mel, B, T, C, seed, n_iter, momentum, wave, rest, workspace_bytes - mel_bytes - wave_bytes, stream)) return rc;
+  return rfx_pcm16(wave, N, C, L, normalize, d_clip_peak, d_pcm_out, stream);
+}
+
 }  // extern "C"

@@ -107,6 +107,8 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     ),
     "rfx_image_decode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rfx_image_encode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rfx_audio_from_image_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "rfx_audio_from_image_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_uint64, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rfx_waveform_from_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_waveform_from_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_uint64, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rfx_image_from_waveform_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
@@ -498,6 +500,31 @@ class Plan:
         check(self.lib.rfx_waveform_from_mel(self.handle, mel.data_ptr(), B, Tn, channels_per_clip, seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
                                              out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
+
+    def audio_from_image(self, img: torch.Tensor, stereo: bool, lut: torch.Tensor, n_iter: int, momentum: float = 0.99, seed: int = 0,
+                         normalize: bool = True, out: T.Optional[torch.Tensor] = None):
+        """spectrogram_image_converter.py:54-91 on the device in one call: (N, n_mels, T, 3) uint8 -> ((N, L, C) int16, per-clip peak (N,));
+        `image_decode` + `waveform_from_mel` (clips of C rows) + `pcm16`, same bytes.  `out` as in `pcm16`."""
+        if img.dtype != torch.uint8 or img.dim() != 4:
+            raise ValueError("expected (N, H, W, 3) uint8 images")
+        img = self._chk(img)
+        lut = self._chk(lut, torch.float32)
+        N, H, W, ch = img.shape
+        if ch != 3 or H != self.n_mels:
+            raise ValueError(f"expected (N, {self.n_mels}, T, 3) uint8 images, got {tuple(img.shape)}")
+        C = 2 if stereo else 1
+        L = self.lib.rfx_griffinlim_output_samples(self.handle, W)
+        if out is not None:
+            if out.device != self.device or out.dtype != torch.int16 or tuple(out.shape) != (N, L, C) or not out.is_contiguous():
+                raise ValueError(f"out must be a contiguous int16 tensor of shape {(N, L, C)} on {self.device}")
+            pcm = out
+        else:
+            pcm = torch.empty((N, L, C), dtype=torch.int16, device=img.device)
+        peak = torch.zeros((N,), dtype=torch.float32, device=img.device)
+        ws = torch.empty(self.lib.rfx_audio_from_image_workspace_bytes(self.handle, N, int(stereo), W), dtype=torch.uint8, device=img.device)
+        check(self.lib.rfx_audio_from_image_u8(self.handle, img.data_ptr(), N, W, int(stereo), lut.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
+                                               int(normalize), peak.data_ptr(), pcm.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        return pcm, peak
 
     def image_from_waveform(self, wave: torch.Tensor, stereo: bool, thresholds: torch.Tensor):
         """spectrogram_image_converter.py:30-51 on the device: (N*C, Lw) float32 -> ((N, n_mels, T, 3) uint8, per-clip max (N,));

@@ -175,13 +175,14 @@ class SpectrogramImageConverter:
             bounds = [(a, min(hi, a + tiles_per_call)) for a in range(lo, hi, tiles_per_call)]  # bounded working set: |S| alone is 19 MB per tile-channel
             source = batch_shard.ChunkSource(imgs, bounds, plan.device)
             for i, (a, b) in enumerate(bounds):
-                mel = plan.image_decode(source.get(i), self.p.stereo, lut)
-                wave = conv._waveform_from_mel(plan, mel, seed=base_seed + 2 * a, channels_per_clip=C)
                 if return_waveform:
+                    mel = plan.image_decode(source.get(i), self.p.stereo, lut)
+                    wave = conv._waveform_from_mel(plan, mel, seed=base_seed + 2 * a, channels_per_clip=C)
                     out = wave.reshape(b - a, C, -1)
-                else:
+                else:  # uint8 tiles -> int16 PCM in one call (rfx_audio_from_image_u8), same bytes as the three calls above + pcm16
                     dst = sink.rows(a - lo, b - lo)  # device sink: the PCM kernel writes the batch rows in place
-                    out = plan.pcm16(wave, channels=C, normalize=True, out=dst)[0]
+                    out = plan.audio_from_image(source.get(i), self.p.stereo, lut, self.p.num_griffin_lim_iters, 0.99, seed=base_seed + 2 * a,
+                                                normalize=True, out=dst)[0]
                 # this chunk's kernels are queued: the host stages and uploads the next chunk underneath them
                 source.prefetch(i + 1)
                 sink.put(a - lo, b - lo, out)

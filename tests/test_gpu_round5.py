@@ -201,3 +201,28 @@ def test_waveform_from_mel_equals_the_two_calls_bit_for_bit(kw, B, cpc, Tn):
     assert one.shape == two.shape == (B, p.hop_length * (Tn - 1)) and bool(torch.isfinite(one).all())
     assert torch.equal(one.view(torch.int32), two.view(torch.int32))
     assert float(one.abs().max()) > 0
+
+
+@pytest.mark.parametrize("kw,stereo,N,Tn", [({}, False, 3, 64), ({}, True, 2, 40), ({"sample_rate": 48000, "max_frequency": 10000}, True, 1, 30)])
+def test_audio_from_image_equals_the_three_calls_byte_for_byte(kw, stereo, N, Tn):
+    """spectrogram_image_converter.py:54-91.  rfx_audio_from_image_u8 keeps the mel amplitudes, the linear magnitudes and the float
+    waveform inside its workspace; the PCM must be what rfx_image_decode_u8 + rfx_inverse_mel + rfx_griffinlim + rfx_pcm16 give."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import image_util
+
+    p = SpectrogramParams(stereo=stereo, num_griffin_lim_iters=4, **kw)
+    plan = _hip.get_plan(p, "cuda")
+    C = 2 if stereo else 1
+    g = torch.Generator(device="cuda").manual_seed(5 + Tn)
+    img = torch.randint(0, 256, (N, p.num_frequencies, Tn, 3), dtype=torch.uint8, device="cuda", generator=g)
+    lut = torch.from_numpy(image_util.decode_lut(float(p.power_for_image), 30e6)).cuda()
+    mel = plan.image_decode(img, stereo, lut)
+    lin = plan.inverse_mel(mel, C, seed=77)
+    wave = plan.griffinlim(lin, N * C, Tn, 4, 0.99, seed=78)
+    pcm3, peak3 = plan.pcm16(wave, channels=C, normalize=True)
+    pcm1, peak1 = plan.audio_from_image(img, stereo, lut, 4, 0.99, seed=77)
+    assert pcm1.shape == pcm3.shape == (N, p.hop_length * (Tn - 1), C) and pcm1.dtype == torch.int16
+    assert torch.equal(peak1.view(torch.int32), peak3.view(torch.int32))
+    assert torch.equal(pcm1, pcm3)
+    assert int(pcm1.abs().max()) > 1000

@@ -498,3 +498,17 @@ def test_c_abi_waveform_from_mel_refuses_null_arguments_before_any_device_call()
     ptr = ctypes.cast(buf, ctypes.c_void_p)
     rc = lib.rfx_waveform_from_mel(None, ptr, 1, 64, 1, 0, 4, ctypes.c_float(0.99), ptr, ptr, 1 << 20, None)
     assert rc != 0 and b"rfx_waveform_from_mel" in lib.rfx_last_error(), (rc, lib.rfx_last_error())
+
+
+def test_c_abi_audio_from_image_refuses_null_arguments_before_any_device_call():
+    """rfx_audio_from_image_u8 (spectrogram_image_converter.py:54-91 in one call): a null plan is RFX_ERR_INVALID, the workspace query 0."""
+    import ctypes
+
+    from riffusion import _hip
+
+    lib = _hip.load_library()
+    assert lib.rfx_audio_from_image_workspace_bytes(None, 2, 0, 64) == 0
+    buf = (ctypes.c_float * 16)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.rfx_audio_from_image_u8(None, ptr, 1, 64, 0, ptr, 0, 4, ctypes.c_float(0.99), 1, ptr, ptr, ptr, 1 << 20, None)
+    assert rc != 0 and b"rfx_audio_from_image_u8" in lib.rfx_last_error(), (rc, lib.rfx_last_error())
