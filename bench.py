@@ -680,6 +680,9 @@ def main():
     gl_ws = torch.empty(plan.lib.rfx_griffinlim_workspace_bytes(plan.handle, B, T), dtype=torch.uint8, device=dev)
 
     def step(seed, launch_ms=None):
+        # the four stages as separate calls with a Griffin-Lim workspace that lives across the steps (rfx_audio_from_image_u8 is the
+        # same work in one call, byte-identical - tests/test_gpu_round5.py - but takes its 1.7 GB workspace from torch's caching
+        # allocator every call: one step in twenty then waits 20 ms for a hipMalloc, which is the allocator's time, not the path's)
         mel = plan.image_decode(tiles, False, lut)                       # (B, 512, T) float32
         lin = plan.inverse_mel(mel, 1, seed=seed)                        # slots
         wave = plan.griffinlim(lin, B, T, args.iters, 0.99, seed=seed + 1, workspace=gl_ws, launch_ms=launch_ms)
