@@ -501,8 +501,12 @@ class Plan:
                                              out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
+    def audio_from_image_workspace(self, N: int, stereo: bool, Tn: int) -> torch.Tensor:
+        """A workspace for `audio_from_image` calls of up to N images of Tn frames (a caller that converts chunk after chunk keeps one)."""
+        return torch.empty(self.lib.rfx_audio_from_image_workspace_bytes(self.handle, N, int(stereo), Tn), dtype=torch.uint8, device=self.device)
+
     def audio_from_image(self, img: torch.Tensor, stereo: bool, lut: torch.Tensor, n_iter: int, momentum: float = 0.99, seed: int = 0,
-                         normalize: bool = True, out: T.Optional[torch.Tensor] = None):
+                         normalize: bool = True, out: T.Optional[torch.Tensor] = None, workspace: T.Optional[torch.Tensor] = None):
         """spectrogram_image_converter.py:54-91 on the device in one call: (N, n_mels, T, 3) uint8 -> ((N, L, C) int16, per-clip peak (N,));
         `image_decode` + `waveform_from_mel` (clips of C rows) + `pcm16`, same bytes.  `out` as in `pcm16`."""
         if img.dtype != torch.uint8 or img.dim() != 4:
@@ -521,7 +525,10 @@ class Plan:
         else:
             pcm = torch.empty((N, L, C), dtype=torch.int16, device=img.device)
         peak = torch.zeros((N,), dtype=torch.float32, device=img.device)
-        ws = torch.empty(self.lib.rfx_audio_from_image_workspace_bytes(self.handle, N, int(stereo), W), dtype=torch.uint8, device=img.device)
+        need = self.lib.rfx_audio_from_image_workspace_bytes(self.handle, N, int(stereo), W)
+        ws = self._chk(workspace) if workspace is not None else None
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=img.device)
         check(self.lib.rfx_audio_from_image_u8(self.handle, img.data_ptr(), N, W, int(stereo), lut.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
                                                int(normalize), peak.data_ptr(), pcm.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return pcm, peak
