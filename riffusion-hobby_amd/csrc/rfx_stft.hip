@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) { 
 //    product.  stft_mel_kernel fetched a weight and an address per product from L2 in dependent steps of eight (7 976 x 2
 //    loads per frame and workgroup).
 // Cost: two more workgroup barriers per frame (all waves must have left P3 before the cube is overwritten with products).
-// Measured (B = 64, T = 512): 0.83 -> 0.69 ms; ablations: transform alone 0.46 ms, + product exchange 0.58 ms.
+// Measured (B = 64, T = 512, round 3): 0.83 -> 0.69 ms.
 // KBMASK: the kb (of a thread's 21 slots) that can contribute, as a compile-time set (rfx_kernels.h: kKbMaskLow / kKbMaskAll).
 // Round 5: what the mel half costs is its TABLE TRAFFIC, not the exchange (profiles/r05_forward_ablation.txt): every frame each
 // thread re-fetches 392 B of frame-invariant constants from L2 (no registers to keep them: 128 VGPRs), 152 B of them for the mel
@@ -270,17 +270,19 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) { 
 // 16-bit LDS byte addresses (two per dword), both segments of a filter in one 8-byte load, the second array at a compile-time
 // offset (one address register serves both stores), the second filter's segments fetched by the first wave only; and for
 // every form the g(n')^k1 twiddles of the rows 11..19 are derived from those of the rows 1..10 and 20 (g^(20-k) = g^20 conj(g^k),
-// as the row-family kernels do: nine packed complex products instead of 72 B per thread and frame).
+// as the row-family kernels do: nine packed complex products instead of 72 B per thread and frame).  With the twiddle table
+// shorter by 18 registers the ten-slot forms also keep their Hann samples in registers and slide their input window (one new sample
+// per frame): 172 B in 22 loads per thread and frame instead of 392 B in 66, 0.554 -> 0.500 ms, 118 VGPRs, no scratch.
 #ifndef RFX_FWD_ABL
-#define RFX_FWD_ABL 0  // timing ablations of -DRFX_ABLATION builds (wrong results): 2 no product scatter, 3 no segment sums,
-#endif                 // 4 transform + table fetches only, 5 no mel tables either
+#define RFX_FWD_ABL 0  // timing ablations of -DRFX_ABLATION builds (wrong results): 2 no product scatter, 3 no segment sums, 4 transform +
+#endif                 // table fetches only, 5 no mel tables either, 7 no slot weights, 8 no twiddle fetches (profiles/r05_forward_ablation.txt)
 #ifndef RFX_FWD_OPT
-#define RFX_FWD_OPT 15  // bit 0: packed mel tables (PK), bit 1: short twiddle table, bits 2-4 below (bit 4 measured 0.503 -> 0.500 ms and
-#endif                  // costs the nine registers the running maximum of rfx_image_from_waveform needs: off)
-constexpr bool kFwdTwShort = (RFX_FWD_OPT & 2) != 0;
-constexpr bool kFwdWinRegs = (RFX_FWD_OPT & 4) != 0;  // (kernels with ten contributing slots per thread: ) the ten Hann samples stay in registers over the run
-constexpr bool kFwdSlide = (RFX_FWD_OPT & 8) != 0;    // ... and the input is a sliding window: one new sample per frame
-constexpr bool kFwdIdxRegs = (RFX_FWD_OPT & 16) != 0; // PK: the packed positions / padding / segments stay in registers over the run
+#define RFX_FWD_OPT 15  // what each bit buys is in profiles/r05_forward_ablation.txt; bit 4 (0.503 -> 0.500 ms) is off: it costs the nine
+#endif                  // registers the running maximum of rfx_image_from_waveform needs
+constexpr bool kFwdTwShort = (RFX_FWD_OPT & 2) != 0;   // eleven twiddles fetched, nine derived (bit 0: the packed tables, see launch_stft_mel)
+constexpr bool kFwdWinRegs = (RFX_FWD_OPT & 4) != 0;   // ten-slot forms: the ten Hann samples stay in registers over the run
+constexpr bool kFwdSlide = (RFX_FWD_OPT & 8) != 0;     // ten-slot forms: sliding input window, one new sample per frame
+constexpr bool kFwdIdxRegs = (RFX_FWD_OPT & 16) != 0;  // PK: the packed positions / padding / segments stay in registers over the run
 template <unsigned KBMASK, bool PK>
 __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
