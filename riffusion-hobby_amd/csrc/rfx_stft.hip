@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel_kernel(StftMelArgs a) { 
 // every form the g(n')^k1 twiddles of the rows 11..19 are derived from those of the rows 1..10 and 20 (g^(20-k) = g^20 conj(g^k),
 // as the row-family kernels do: nine packed complex products instead of 72 B per thread and frame).  With the twiddle table
 // shorter by 18 registers the ten-slot forms also keep their Hann samples in registers and slide their input window (one new sample
-// per frame): 172 B in 22 loads per thread and frame instead of 392 B in 66, 0.554 -> 0.500 ms, 118 VGPRs, no scratch.
+// per frame): 208 B in 29 loads per thread and frame instead of 392 B in 66, 0.554 -> 0.503 ms, 118 VGPRs, no scratch.
 #ifndef RFX_FWD_ABL
 #define RFX_FWD_ABL 0  // timing ablations of -DRFX_ABLATION builds (wrong results): 2 no product scatter, 3 no segment sums, 4 transform +
 #endif                 // table fetches only, 5 no mel tables either, 7 no slot weights, 8 no twiddle fetches (profiles/r05_forward_ablation.txt)

@@ -73,6 +73,10 @@ def test_forward_and_sgd_kernels_hold_no_scratch(asm):
     fwd = kernel_symbols(asm["rfx_stft.hip"], r"stft_mel2_kernelILj2031647ELb1")
     assert len(fwd) == 1
     assert scratch_bytes(asm["rfx_stft.hip"], fwd[0]) == 0
+    # ... and fetches 29 values per thread and frame, 30 in the wave that carries the second filters (66 until round 5, when those fetches - not the exchange - turned out to be what
+    # the mel half of the kernel cost: profiles/r05_forward_ablation.txt)
+    loads = [l for l in frame_loop(asm["rfx_stft.hip"], fwd[0]) if re.match(r"\s+buffer_load", l)]
+    assert 26 <= len(loads) <= 30, len(loads)
     wave = kernel_symbols(asm["rfx_imel.hip"], r"imel_wave_kernel")
     assert len(wave) == 2
     for sym in wave:
