@@ -4,7 +4,8 @@ Register / scratch / LDS use of every kernel of the library, read from the ISA h
     python tools/isa_resources.py [file.hip ...]     -> one line per kernel, and profiles/isa_resources_latest.json
 
 A kernel with private_segment_fixed_size > 0 spills (or indexes a local array dynamically): the round-4 review listed the
-48 kHz row-family kernels and the one-tile Griffin-Lim kernels; tests/test_isa_resources.py holds the list at zero.
+48 kHz row-family kernels and the one-tile Griffin-Lim kernels; tests/test_isa_resources.py holds the hot kernels' frame loops
+free of scratch traffic (and the forward kernel's per-frame load count).
 """
 import json, os, re, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
