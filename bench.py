@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--host-input", action="store_true",
                     help="decode-stereo64: the timed calls take the tiles from HOST memory (the reference's API is host images in, host "
                          "audio out); uploads run chunk by chunk through pinned memory on a side stream (batch_shard.ChunkSource)")
+    ap.add_argument("--n1-ms", type=float, default=None,
+                    help="ms_per_step of the same command at --gpus 1: an N > 1 line then carries `vs_n1` (weak scaling: t1 / tN)")
     ap.add_argument("--gather", choices=["none", "rank0", "all"], default="none",
                     help="decode-stereo64: which clips a rank returns (own shard / everything on rank 0 / everything everywhere)")
     return ap.parse_args()
@@ -281,18 +283,47 @@ class ClockSampler:
         return out
 
 
-def kernel_source_fingerprint(files=("rfx_gl.hip", "rfx_core.h", "rfx_frame.hip.h")) -> str:
-    """sha1 over the sources the dominant kernel is compiled from (the GPU box and the driver's checkout have no .git): the PMC
-    summaries carry the fingerprint of the sources they were collected on, and a line whose sources differ says `stale`."""
+def strip_comments_and_space(src: str) -> str:
+    """C / C++ source without comments and without white space (string and character literals kept as they are): what is left
+    changes only when the code does."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == "/" and i + 1 < n and src[i + 1] == "/":
+            while i < n and src[i] != "\n":
+                i += 1
+        elif c == "/" and i + 1 < n and src[i + 1] == "*":
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        elif c in "\"'":
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i : j + 1])
+            i = j + 1
+        elif c.isspace():
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def kernel_source_fingerprint(files=("rfx_gl.hip", "rfx_core.h", "rfx_frame.hip.h", "rfx_kernels.h")) -> str:
+    """sha1 over the CODE of the sources the dominant kernel is compiled from - comments and white space stripped (round 6: two
+    comment-only commits had flipped the `stale` flag of round 5's line) - the GPU box and the driver's checkout have no .git:
+    the PMC summaries carry the fingerprint of the sources they were collected on (tools/profile_round.sh calls this function),
+    and a line whose sources differ says `stale`."""
     import hashlib
 
     h = hashlib.sha1()
     for name in files:
         try:
-            with open(os.path.join(ROOT, "riffusion-hobby_amd", "csrc", name), "rb") as f:
-                h.update(f.read())
+            with open(os.path.join(ROOT, "riffusion-hobby_amd", "csrc", name), "r", encoding="utf-8", errors="replace") as f:
+                h.update(strip_comments_and_space(f.read()).encode())
         except OSError:
             h.update(b"?")
+        h.update(b"\0")
     return h.hexdigest()[:12]
 
 
@@ -328,7 +359,21 @@ def cpu_baseline(iters: int, threads_cap: int = 16, min_seconds: float = 10.0, m
         t_gl += t2 - t1
         n += 1
     total = t_imel + t_gl
+    # BASELINE.json configs[0] on the CPU: the oracle on og_beat.png (image decode -> InverseMelScale -> Griffin-Lim -> int16), one call
+    og_s = None
+    try:
+        from PIL import Image
+
+        og = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "og_beat.png")).convert("RGB"))
+        t0 = time.time()
+        mel = torch.from_numpy(O.spectrogram_from_image_u8(og, 0.25, False, 30e6))
+        wave = O.griffinlim(O.inverse_mel_scale_sgd(mel, p, generator=g), p, generator=g)
+        O.pcm16_from_waveform(wave.numpy(), normalize=True)
+        og_s = round(time.time() - t0, 3)
+    except Exception as exc:  # (a baseline figure, not worth failing the line for)
+        og_s = f"failed: {exc}"
     return {
+        "og_beat_s": og_s,
         "value": round(n / total, 5),
         "unit": "tiles/s",
         "cores": threads,
@@ -339,6 +384,7 @@ def cpu_baseline(iters: int, threads_cap: int = 16, min_seconds: float = 10.0, m
     }
 
 
+FORWARD_KERNEL_SOURCES = ("rfx_stft.hip", "rfx_core.h", "rfx_frame.hip.h", "rfx_kernels.h", "rfx_codec.hip")
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
@@ -465,7 +511,7 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
                         "neither HBM nor the MFMA pipes bound this kernel: `frac` (HBM) is small by construction, true_flops_frac prices the "
                         "flops actually executed against the 157.3 TFLOP/s fp32 peak, and `binding` (occupancy of the fp32 VALU pipes) is the resource that bounds it; "
                         "avg_launch_ms is one launch between two stream drains (HIP events)"}
-        fp_here = kernel_source_fingerprint(("rfx_stft.hip", "rfx_core.h", "rfx_frame.hip.h"))
+        fp_here = kernel_source_fingerprint(FORWARD_KERNEL_SOURCES)
         roof["from_profiles"] = {"source": pmc_src, "git": profile_rev(fpmc, pmc_src) if fpmc else None, "kernel_sources_of_summary": fpmc.get("src_sha"),
                                  "kernel_sources_here": fp_here, "stale": fpmc.get("src_sha") != fp_here}
         valu = fpmc.get("SQ_INSTS_VALU_per_launch")
@@ -506,6 +552,40 @@ def forward_measure(args, world, rank, dev, distributed, with_cpu):
             out["cpu_baseline"] = forward_cpu_baseline()
         return out
     return None
+
+
+def og_beat_cli(dev, reps: int = 5):
+    """BASELINE.json configs[0], the GPU half: what `python -m riffusion.cli image-to-audio --image seed_images/og_beat.png --audio x.wav`
+    does (reference cli.py:73-95), in process: PNG file -> EXIF -> SpectrogramParams -> SpectrogramImageConverter ->
+    audio_from_spectrogram_image(apply_filters=True) -> WAV bytes.  Median of `reps` after one warm-up (plan and arena exist, as
+    in a server; the very first call of a process also builds the plan: reported separately)."""
+    import io
+
+    from PIL import Image
+
+    from riffusion import cli
+    from riffusion.spectrogram_image_converter import SpectrogramImageConverter
+
+    path = os.path.join(ROOT, "tests", "golden", "og_beat.png")
+
+    def once():
+        t0 = time.perf_counter()
+        pil = Image.open(path)
+        params = cli._params_from_image(pil)
+        converter = SpectrogramImageConverter(params=params, device=str(dev))
+        segment = converter.audio_from_spectrogram_image(pil, apply_filters=True)
+        buf = io.BytesIO()
+        segment.export(buf, format="wav")
+        return time.perf_counter() - t0, len(buf.getvalue()), segment.duration_seconds
+
+    first, nbytes, seconds = once()
+    times = sorted(once()[0] for _ in range(reps))
+    return {"ms": round(times[len(times) // 2] * 1e3, 3), "ms_min": round(times[0] * 1e3, 3), "ms_max": round(times[-1] * 1e3, 3),
+            "first_call_ms": round(first * 1e3, 3), "reps": reps, "wav_bytes": nbytes, "audio_seconds": round(seconds, 3),
+            "audio_sec_per_sec": round(seconds / times[len(times) // 2], 1),
+            "workload": "riffusion.cli image-to-audio on tests/golden/og_beat.png (= the reference's seed_images/og_beat.png), in process: PNG decode -> "
+                        "EXIF params -> audio_from_spectrogram_image(apply_filters=True) -> WAV bytes; mono 44.1 kHz, Griffin-Lim 32, one tile "
+                        "(BASELINE.json configs[0] on the GPU; the oracle's CPU time for the same image is cpu_baseline.og_beat_s)"}
 
 
 def stereo64_main(args, world, rank, dev, distributed):
@@ -666,10 +746,12 @@ def main():
         return finish(stereo64_main(args, world, rank, dev, distributed))
 
     from riffusion import _hip
+    from riffusion.spectrogram_image_converter import SpectrogramImageConverter
     from riffusion.spectrogram_params import SpectrogramParams
     from riffusion.util import image_util
 
     params = SpectrogramParams(num_griffin_lim_iters=args.iters)
+    conv = SpectrogramImageConverter(params, device=str(dev))
     plan = _hip.get_plan(params, dev)
     B, T = args.batch, N_FRAMES
 
@@ -679,10 +761,15 @@ def main():
     lut = torch.from_numpy(image_util.decode_lut(0.25, 30e6)).to(dev)
     gl_ws = torch.empty(plan.lib.rfx_griffinlim_workspace_bytes(plan.handle, B, T), dtype=torch.uint8, device=dev)
 
-    def step(seed, launch_ms=None):
-        # the four stages as separate calls with a Griffin-Lim workspace that lives across the steps (rfx_audio_from_image_u8 is the
-        # same work in one call, byte-identical - tests/test_gpu_round5.py - but takes its 1.7 GB workspace from torch's caching
-        # allocator every call: one step in twenty then waits 20 ms for a hipMalloc, which is the allocator's time, not the path's)
+    def step(seed):
+        # THE PRODUCT ENTRY POINT (round 6): what a caller of the reference's SpectrogramImageConverter.audio_from_spectrogram_image
+        # (spectrogram_image_converter.py:65-91) reaches for a batch - one Python call, one C call (rfx_audio_from_image_u8_ex),
+        # uint8 tiles in HBM -> int16 PCM in HBM, scratch space from the plan's arena (no allocator traffic in steady state)
+        return conv.audio_from_spectrogram_images(tiles, seed=seed, return_device=True, tiles_per_call=B)
+
+    def four_calls(seed, launch_ms=None):
+        # the same work as four C calls with a Griffin-Lim workspace hoisted out of the step: the headline of rounds 1-5, kept as
+        # stages.c_abi_four_calls_ms (the product call must not cost more)
         mel = plan.image_decode(tiles, False, lut)                       # (B, 512, T) float32
         lin = plan.inverse_mel(mel, 1, seed=seed)                        # slots
         wave = plan.griffinlim(lin, B, T, args.iters, 0.99, seed=seed + 1, workspace=gl_ws, launch_ms=launch_ms)
@@ -710,11 +797,14 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     clock.stop()
+    per_rank_ms = None
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert bool(torch.isfinite(pcm.float()).all())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # each rank's own wall time of the K steps (the value uses the MAX, per the contract)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)
+    assert pcm.shape == (B, HOP * (T - 1), 1) and pcm.dtype == torch.int16 and int(pcm.abs().max()) > 30000
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     # ---- roofline leg (outside the timed region): per-launch durations from HIP events on the stream
@@ -722,7 +812,7 @@ def main():
     extra = {}
     if rank == 0:
         ms = (ctypes.c_float * (args.iters + 1))()
-        step(999, launch_ms=ms)
+        four_calls(999, launch_ms=ms)
         steady = [ms[i] for i in range(2, args.iters + 1)] or [ms[-1]]
         avg_ms = sum(steady) / len(steady)
         alg_bytes = 20.0 * N_BINS * T * B
@@ -788,6 +878,21 @@ def main():
         names = ["image_decode_ms", "inverse_mel_ms", "griffinlim_ms", "pcm16_ms"]
         extra = {n: round(evs[i].elapsed_time(evs[i + 1]), 3) for i, n in enumerate(names)}
         extra["griffinlim_only_tiles_per_s"] = round(B / (extra["griffinlim_ms"] * 1e-3), 1)
+        # the four-call form of the step (rounds 1-5's headline) and the product call, side by side, same box, same minute
+        n4 = max(3, min(args.steps, 10))
+        for fn, key in ((four_calls, "c_abi_four_calls_ms"), (step, "product_call_ms")):
+            fn(0)
+            torch.cuda.synchronize(dev)
+            t4 = time.perf_counter()
+            for k in range(n4):
+                fn(200 + k)
+            torch.cuda.synchronize(dev)
+            extra[key] = round((time.perf_counter() - t4) / n4 * 1e3, 3)
+        extra["note"] = ("the timed step is ONE SpectrogramImageConverter.audio_from_spectrogram_images(tiles, return_device=True) call = one "
+                         "rfx_audio_from_image_u8_ex; c_abi_four_calls_ms is the same work as rfx_image_decode_u8 + rfx_inverse_mel + rfx_griffinlim + "
+                         f"rfx_pcm16 with a workspace hoisted out of the step (the headline of rounds 1-5), product_call_ms the timed step again, {n4} steps each")
+        arena = plan.arena
+        extra["workspace_arena"] = {"buffers_allocated_in_this_process": arena.allocations, "idle_bytes": arena.idle_bytes()}
 
     ms_per_step = elapsed / args.steps * 1e3
     tiles_per_s = world * B * args.steps / elapsed
@@ -807,6 +912,7 @@ def main():
             "ms_per_step_min": round(per_step[0], 3),
             "ms_per_step_median": round(per_step[len(per_step) // 2], 3),
             "ms_per_step_max": round(per_step[-1], 3),
+            "ms_per_step_max_over_min": round(per_step[-1] / per_step[0], 4),
             "shader_clock": clock.summary(),
             "higher_is_better": True,
             "scaling": "weak",
@@ -815,7 +921,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B} synthetic 512x512 mono uint8 tiles -> image decode -> InverseMelScale SGD-200 -> "
-                f"Griffin-Lim {args.iters} -> int16 PCM (BASELINE.json configs[1]); tiles resident in HBM",
+                f"Griffin-Lim {args.iters} -> int16 PCM (BASELINE.json configs[1]); tiles resident in HBM; one product call per step "
+                "(SpectrogramImageConverter.audio_from_spectrogram_images -> rfx_audio_from_image_u8_ex)",
                 "batch_per_gpu": B,
                 "global_batch": world * B,
                 "griffin_lim_iters": args.iters,
@@ -825,6 +932,12 @@ def main():
             "roofline": roofline,
             "stages": extra,
         }
+        if per_rank_ms is not None:
+            out["per_rank_ms"] = {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3), "by_rank": [round(v, 3) for v in per_rank_ms]}
+        if args.n1_ms:
+            out["vs_n1"] = {"n1_ms": args.n1_ms, "weak_scaling_efficiency": round(args.n1_ms / ms_per_step, 4),
+                            "speedup": round(n_ranks * args.n1_ms / ms_per_step, 3),
+                            "note": "weak scaling: every rank converts its own batch; speedup = N x t1 / tN"}
     # ---- the one-tile-per-request case (reference server.py:152-164): uint8 tile in HBM -> int16 PCM on the host, one call
     latency = None
     if rank == 0:
@@ -916,6 +1029,8 @@ def main():
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": alg64, "achieved": round(alg64 / dt64 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg64 / dt64 / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "canonical bytes of SURVEY 8(d) for the WHOLE step (InverseMelScale and the codecs included in the time, not in the bytes)"}}
+        with stdout_to_stderr():  # (the CLI prints its "no EXIF, using defaults" warning to stdout, like the reference's)
+            other_cfg["og_beat_cli"] = og_beat_cli(dev)
         sweep = {}
         for Bs in (16, 48, 64, 65, 96, 100, 128):
             tl = torch.from_numpy(np.random.default_rng(Bs).integers(0, 256, size=(Bs, N_MELS, T, 3), dtype=np.uint8)).to(dev)

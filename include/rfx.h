@@ -134,6 +134,24 @@ int64_t rfx_debug_run_start(int64_t b, int64_t runs, int64_t n_frames, int64_t h
  * Every forward entry point below produces exactly this many frames. */
 int rfx_stft_frames(const rfx_plan* plan, int Lw);
 
+/* Per-call options of the inverse entry points (round 6; the *_ex forms below; NULL = defaults = the plain forms).
+ * Set struct_size = sizeof(rfx_call_options) and zero everything you do not use.
+ *
+ * row_base: index, in the caller's WHOLE batch, of the first row (clip-channel) this call converts.  The random starts the
+ *   reference draws from torch's global generator (spectrogram_converter.py:72 rand_init=True; torchaudio InverseMelScale's
+ *   torch.rand) are drawn here from (seed, row_base + r, frame, bin) for row r of the call.  With the same seed, a batch converted
+ *   in one call, in chunks (row_base = rows before the chunk) or sharded over the GPUs of a node gives the same audio for every clip,
+ *   bit for bit: nothing else in a clip's arithmetic depends on the batch it travels in (csrc/rfx_kernels.h: kGlGroup).
+ *   Must be a multiple of channels_per_clip where the entry point has one.
+ * magnitude_hint: see "Numeric range" below; 0 = not given. */
+typedef struct {
+  uint32_t struct_size;
+  uint32_t flags;           /* must be 0 */
+  uint64_t row_base;
+  float magnitude_hint;
+  float reserved;           /* must be 0 */
+} rfx_call_options;
+
 /* ---- layout converters ------------------------------------------------------------------- */
 /* (B, n_stft, T) float32 magnitudes -> slots (float32) */
 int rfx_pack_magnitudes(const rfx_plan* plan, const float* d_lin_bft, int B, int T, float* d_slots, void* stream);
@@ -162,6 +180,12 @@ int rfx_griffinlim_output_samples(const rfx_plan* plan, int T);
 int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
                    int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
                    void* stream);
+
+/* rfx_griffinlim with per-call options (NULL = rfx_griffinlim) and, when h_launch_ms != NULL, rfx_griffinlim_timed's
+ * per-launch durations (it then synchronises the stream). */
+int rfx_griffinlim_ex(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                      int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                      void* stream, const rfx_call_options* options, float* h_launch_ms);
 
 /* Same as rfx_griffinlim, but brackets every kernel launch with HIP events recorded on `stream`
  * and, after synchronising, writes the n_iter+1 launch durations (ms; [0] = the init ISTFT, [1] the
@@ -221,6 +245,10 @@ size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T);
 int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                     uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream);
 
+int rfx_inverse_mel_ex(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
+                       uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream,
+                       const rfx_call_options* options);
+
 /* ---- inverse, in one call: SpectrogramConverter.waveform_from_mel_amplitudes, spectrogram_converter.py:187-204
  * (`self.inverse_mel_scaler(amplitudes_mel)` :201 then `self.inverse_spectrogram_func(amplitudes_linear)` :204).
  * d_mel (B, n_mels, T) -> d_wave_out (B, rfx_griffinlim_output_samples(plan, T)); clips of `channels_per_clip` rows as in
@@ -229,6 +257,10 @@ int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int 
 size_t rfx_waveform_from_mel_workspace_bytes(const rfx_plan* plan, int B, int T);
 int rfx_waveform_from_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
                           float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
+int rfx_waveform_from_mel_ex(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
+                             float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream,
+                             const rfx_call_options* options);
 
 /* ---- image codec: riffusion/util/image_util.py -----------------------------------------------
  * decode = spectrogram_from_image (:81-108): d_img (N, H, W, 3) uint8 RGB -> (N*C, H, W) float32,
@@ -258,6 +290,11 @@ size_t rfx_audio_from_image_workspace_bytes(const rfx_plan* plan, int N, int ste
 int rfx_audio_from_image_u8(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
                             int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
                             size_t workspace_bytes, void* stream);
+
+/* options->row_base counts ROWS (clip-channels): the call's first image is image row_base / C of the caller's batch */
+int rfx_audio_from_image_u8_ex(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
+                               int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
+                               size_t workspace_bytes, void* stream, const rfx_call_options* options);
 
 #ifdef __cplusplus
 }

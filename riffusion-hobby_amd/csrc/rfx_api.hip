@@ -933,15 +933,18 @@ static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
 // that join them that much shorter (rfx_kernels.h, GlArgs::run_h) - only when every CU gets exactly its two workgroups (the case
 // that was measured) and the short runs keep 11 frames; otherwise all runs are equal (+- 1 frame).  which = 0: the synthesis-only
 // first launch, 1: the iterations.
+// Round 6: the unit of the partition is the GROUP (kGlGroup = 16 consecutive frames of a row, rfx_kernels.h): runs are whole groups,
+// at most one run per slot and never more runs than groups.  A clip's bits no longer depend on the partition at all (every group
+// boundary splits the overlap-add chains, inside a run as between runs), so the partition is free to follow the chip and the batch.
 struct GlPartition { int runs, h, w1, w2; };
 static GlPartition gl_partition(const rfx_plan* plan, int B, int T, int which) {
-  const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu, N = (long long)B * T;
-  long long nruns = N / 10;
+  const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu, N = (long long)B * rfx::gl_groups_per_row(T);
+  long long nruns = N;
   if (nruns > slots) nruns = slots;
   if (nruns < 1) nruns = 1;
   int skew = plan->gl_run_skew[which ? 1 : 0];
   const bool full = plan->gl_wgs_per_cu == 2 && nruns == slots;
-  if (!full || skew < 0 || skew > 400 || (N * (1000 - skew)) / (1000LL * nruns) < 11) skew = 0;
+  if (!full || skew < 0 || skew > 400 || (N * (1000 - skew)) / (1000LL * nruns) < 2) skew = 0;
   return GlPartition{(int)nruns, plan->num_cus, 1000 + skew, 1000 - skew};
 }
 
@@ -949,7 +952,7 @@ int rfx_griffinlim_runs(const rfx_plan* plan, int B, int T, int which, int64_t* 
   if (!plan || B <= 0 || T < 2 || plan->generic) return 0;
   const GlPartition p = gl_partition(plan, B, T, which);
   if (run_starts)
-    for (int b = 0; b <= p.runs && b < capacity; ++b) run_starts[b] = rfx::gl_run_start(b, p.runs, (long long)B * T, p.h, p.w1, p.w2);
+    for (int b = 0; b <= p.runs && b < capacity; ++b) run_starts[b] = rfx::gl_run_start_frame(b, p.runs, B, T, p.h, p.w1, p.w2);
   return p.runs;
 }
 
@@ -994,11 +997,29 @@ static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames
   total = o;
 }
 
+// rfx_call_options as the entry points below see them (NULL / short struct = defaults)
+struct CallOpt {
+  uint64_t row_base = 0;
+  float magnitude_hint = 0.f;
+};
+static int read_call_options(const rfx_call_options* o, CallOpt* out, const char* who) {
+  *out = CallOpt{};
+  if (!o) return RFX_OK;
+  if (o->struct_size < offsetof(rfx_call_options, row_base) + sizeof(uint64_t))
+    return fail(RFX_ERR_INVALID, std::string(who) + ": rfx_call_options.struct_size is not set");
+  if (o->flags != 0) return fail(RFX_ERR_INVALID, std::string(who) + ": rfx_call_options.flags must be 0");
+  out->row_base = o->row_base;
+  if (o->struct_size >= offsetof(rfx_call_options, magnitude_hint) + sizeof(float)) out->magnitude_hint = o->magnitude_hint;
+  if (!(out->magnitude_hint >= 0.f) || out->magnitude_hint > 3.0e38f)
+    return fail(RFX_ERR_INVALID, std::string(who) + ": rfx_call_options.magnitude_hint must be a finite value >= 0");
+  return RFX_OK;
+}
+
 // mag_in_fam_slots (rfx_waveform_from_mel on a row-family plan): d_mag already holds the family kernels' slot order [B*T][fsf] -
 // InverseMelScale wrote it that way - so the once-per-call re-ordering of the plain frames is left out
 static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* d_angles0, uint64_t seed, int B, int T, int n_iter,
                           float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream,
-                          float* h_launch_ms, bool mag_in_fam_slots = false) {
+                          float* h_launch_ms, const CallOpt& opt, bool mag_in_fam_slots = false) {
   const GenGeom& g = plan->gg;
   const int L = gen_out_len(g, T);
   if (n_iter > 0 && L <= g.n_fft / 2)
@@ -1043,6 +1064,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     fa.win = plan->d_win;
     fa.mom = momentum / (1.f + momentum);
     fa.seed = seed;
+    fa.frame_base = opt.row_base * (uint64_t)T;
     fa.B = B;
     fa.T = T;
     fa.L = L;
@@ -1074,6 +1096,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   a.frames = frames;
   a.mom = momentum / (1.f + momentum);
   a.seed = seed;
+  a.frame_base = opt.row_base * (uint64_t)T;
   a.B = B;
   a.T = T;
   a.L = L;
@@ -1113,7 +1136,7 @@ size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
 
 static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
                            int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
-                           void* stream_, float* h_launch_ms) {
+                           void* stream_, float* h_launch_ms, const CallOpt& opt) {
   if (!plan || !d_mag_slots || !d_wave_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_griffinlim: null argument");
   if (B <= 0 || T < 2 || n_iter < 0) return fail(RFX_ERR_INVALID, "rfx_griffinlim: bad shape");
   if ((long long)B * T > 0x7fffffffLL) return fail(RFX_ERR_INVALID, "rfx_griffinlim: more than 2^31 - 1 frames in one call");
@@ -1121,7 +1144,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   if (plan->generic) {
     RFX_ON_DEVICE(plan->device);
     return gen_griffinlim(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace, workspace_bytes,
-                          (hipStream_t)stream_, h_launch_ms);
+                          (hipStream_t)stream_, h_launch_ms, opt);
   }
   // every iteration re-analyses the hop*(T-1)-sample estimate with torch.stft(center=True, reflect):
   // the reference raises there unless the signal is longer than the n_fft/2 padding
@@ -1160,6 +1183,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
     fa.Lpad = Lpad;
     fa.mom = momentum / (1.f + momentum);
     fa.seed = seed;
+    fa.frame_base = opt.row_base * (uint64_t)T;
     const long long nframes = (long long)B * T;
     const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu;
     const int nblocks = (int)(nframes < slots ? nframes : slots);
@@ -1173,7 +1197,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
       fa.audio_prev = gen[(it + 1) % 3][0];  // x_{it-2}
       RFX_HIP(launch_gl_frame(it == 0 ? 0 : it == 1 ? 1 : 2, fa, nblocks, stream));
       const bool last = it == n_iter;
-      RFX_HIP(launch_gl_fold(fa.frames, scale, last ? d_wave_out : gen[it % 3][0], B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
+      RFX_HIP(launch_gl_fold(fa.frames, plan->d_win, scale, last ? d_wave_out : gen[it % 3][0], B, T, L, last ? (size_t)L : (size_t)Lpad, stream));
       if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
     }
     if (h_launch_ms) {
@@ -1196,6 +1220,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   g.Lpad = Lpad;
   g.mom = momentum / (1.f + momentum);
   g.seed = seed;
+  g.frame_base = opt.row_base * (uint64_t)T;
   g.timing = plan->timing;
   // runs: the batch's B*T frames, counted clip after clip, are cut into one run per resident workgroup slot (gl_partition)
   GlPartition part = gl_partition(plan, B, T, 0);
@@ -1252,7 +1277,16 @@ int rfx_griffinlim(const rfx_plan* plan, const float* d_mag_slots, const void* d
                    int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
                    void* stream) {
   return griffinlim_impl(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace,
-                         workspace_bytes, stream, nullptr);
+                         workspace_bytes, stream, nullptr, CallOpt{});
+}
+
+int rfx_griffinlim_ex(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
+                      int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
+                      void* stream, const rfx_call_options* options, float* h_launch_ms) {
+  CallOpt opt;
+  if (int rc = read_call_options(options, &opt, "rfx_griffinlim_ex")) return rc;
+  return griffinlim_impl(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace,
+                         workspace_bytes, stream, h_launch_ms, opt);
 }
 
 int rfx_griffinlim_timed(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
@@ -1260,7 +1294,7 @@ int rfx_griffinlim_timed(const rfx_plan* plan, const float* d_mag_slots, const v
                          void* stream, float* h_launch_ms) {
   if (!h_launch_ms) return fail(RFX_ERR_INVALID, "rfx_griffinlim_timed: null timing array");
   return griffinlim_impl(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace,
-                         workspace_bytes, stream, h_launch_ms);
+                         workspace_bytes, stream, h_launch_ms, CallOpt{});
 }
 
 int rfx_unpack_magnitudes(const rfx_plan* plan, const float* d_slots, int B, int T, float* d_bft, void* stream) {
@@ -1488,20 +1522,32 @@ static bool imel_can_emit_fam_slots(const rfx_plan* plan) {
 }
 
 static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
-                            uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots);
+                            uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots,
+                            const CallOpt& opt);
 
 int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                     uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_) {
-  return inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, d_spec0, seed, d_mag_slots, d_workspace, workspace_bytes, stream_, false);
+  return inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, d_spec0, seed, d_mag_slots, d_workspace, workspace_bytes, stream_, false, CallOpt{});
+}
+
+int rfx_inverse_mel_ex(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
+                       uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_,
+                       const rfx_call_options* options) {
+  CallOpt opt;
+  if (int rc = read_call_options(options, &opt, "rfx_inverse_mel_ex")) return rc;
+  return inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, d_spec0, seed, d_mag_slots, d_workspace, workspace_bytes, stream_, false, opt);
 }
 
 static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
-                            uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots) {
+                            uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots,
+                            const CallOpt& opt) {
   if (!plan || !d_mel || !d_mag_slots || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: null argument");
   if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: plan was created without a mel filterbank");
   if (!plan->imel_ok) return fail(RFX_ERR_UNSUPPORTED, "rfx_inverse_mel: filterbank is not banded: " + plan->imel_why);
   if (B <= 0 || T <= 0 || channels_per_clip <= 0 || B % channels_per_clip)
     return fail(RFX_ERR_INVALID, "rfx_inverse_mel: batch must be a multiple of channels_per_clip");
+  if (opt.row_base % (uint64_t)channels_per_clip)
+    return fail(RFX_ERR_INVALID, "rfx_inverse_mel: rfx_call_options.row_base must be a multiple of channels_per_clip (clips are not split)");
   if (workspace_bytes < rfx_inverse_mel_workspace_bytes(plan, B, T)) return fail(RFX_ERR_WORKSPACE, "rfx_inverse_mel: workspace too small");
   RFX_ON_DEVICE(plan->device);
   hipStream_t stream = (hipStream_t)stream_;
@@ -1533,6 +1579,7 @@ static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int
   a.lr = 0.1f;        // sgdargs=None -> {"lr": 0.1, "momentum": 0.9} (torchaudio 0.13 InverseMelScale)
   a.momentum = 0.9f;
   a.seed = seed;
+  a.frame_base = opt.row_base * (uint64_t)T;
   if (a.max_iter <= 0) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: max_mel_iters must be positive");
   RFX_HIP(launch_imel(a, plan->imel_variant, stream));
   // reproduce the reference's early exit (tolerance_loss 1e-5, tolerance_change 1e-8,
@@ -1555,8 +1602,24 @@ size_t rfx_waveform_from_mel_workspace_bytes(const rfx_plan* plan, int B, int T)
   return align_up((size_t)B * T * stride * sizeof(float), 256) + (imel > gl ? imel : gl);
 }
 
+static int waveform_from_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
+                                 float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream, const CallOpt& opt);
+
 int rfx_waveform_from_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
                           float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+  return waveform_from_mel_impl(plan, d_mel, B, T, channels_per_clip, seed, n_iter, momentum, d_wave_out, d_workspace, workspace_bytes, stream, CallOpt{});
+}
+
+int rfx_waveform_from_mel_ex(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
+                             float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream,
+                             const rfx_call_options* options) {
+  CallOpt opt;
+  if (int rc = read_call_options(options, &opt, "rfx_waveform_from_mel_ex")) return rc;
+  return waveform_from_mel_impl(plan, d_mel, B, T, channels_per_clip, seed, n_iter, momentum, d_wave_out, d_workspace, workspace_bytes, stream, opt);
+}
+
+static int waveform_from_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
+                                 float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, void* stream, const CallOpt& opt) {
   if (!plan || !d_mel || !d_wave_out || !d_workspace || B <= 0 || T <= 0) return fail(RFX_ERR_INVALID, "rfx_waveform_from_mel: bad argument");
   const size_t need = rfx_waveform_from_mel_workspace_bytes(plan, B, T);
   if (!need) return fail(RFX_ERR_UNSUPPORTED, "rfx_waveform_from_mel: this plan cannot invert (see rfx_inverse_mel / rfx_griffinlim)");
@@ -1567,11 +1630,11 @@ int rfx_waveform_from_mel(const rfx_plan* plan, const float* d_mel, int B, int T
   const bool fam_slots = imel_can_emit_fam_slots(plan);
   const size_t lin_bytes = align_up((size_t)B * T * (fam_slots ? (size_t)plan->fam.fsf : (size_t)plan->frame_stride) * sizeof(float), 256);
   void* rest = (char*)d_workspace + lin_bytes;
-  if (int rc = inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, nullptr, seed, lin, rest, workspace_bytes - lin_bytes, stream, fam_slots)) return rc;
-  if (!fam_slots) return rfx_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, stream);
+  if (int rc = inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, nullptr, seed, lin, rest, workspace_bytes - lin_bytes, stream, fam_slots, opt)) return rc;
+  if (!fam_slots) return griffinlim_impl(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, stream, nullptr, opt);
   if (T < 2 || n_iter < 0 || (long long)B * T > 0x7fffffffLL || !(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_waveform_from_mel: bad shape");
   RFX_ON_DEVICE(plan->device);
-  return gen_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, (hipStream_t)stream, nullptr, true);
+  return gen_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, (hipStream_t)stream, nullptr, opt, true);
 }
 
 int rfx_image_decode_u8(const uint8_t* d_img, int N, int H, int W, int stereo, const float* d_lut256, float* d_mel_out,
@@ -1619,9 +1682,29 @@ size_t rfx_audio_from_image_workspace_bytes(const rfx_plan* plan, int N, int ste
   return align_up((size_t)B * plan->p.n_mels * T * sizeof(float), 256) + align_up((size_t)B * rfx_griffinlim_output_samples(plan, T) * sizeof(float), 256) + inner;
 }
 
+static int audio_from_image_impl(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
+                                int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
+                                size_t workspace_bytes, void* stream, const CallOpt& opt);
+
 int rfx_audio_from_image_u8(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
                             int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
                             size_t workspace_bytes, void* stream) {
+  return audio_from_image_impl(plan, d_img, N, T, stereo, d_lut256, seed, n_iter, momentum, normalize, d_clip_peak, d_pcm_out, d_workspace,
+                               workspace_bytes, stream, CallOpt{});
+}
+
+int rfx_audio_from_image_u8_ex(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
+                               int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
+                               size_t workspace_bytes, void* stream, const rfx_call_options* options) {
+  CallOpt opt;
+  if (int rc = read_call_options(options, &opt, "rfx_audio_from_image_u8_ex")) return rc;
+  return audio_from_image_impl(plan, d_img, N, T, stereo, d_lut256, seed, n_iter, momentum, normalize, d_clip_peak, d_pcm_out, d_workspace,
+                               workspace_bytes, stream, opt);
+}
+
+static int audio_from_image_impl(const rfx_plan* plan, const uint8_t* d_img, int N, int T, int stereo, const float* d_lut256, uint64_t seed,
+                                int n_iter, float momentum, int normalize, float* d_clip_peak, int16_t* d_pcm_out, void* d_workspace,
+                                size_t workspace_bytes, void* stream, const CallOpt& opt) {
   if (!plan || !d_img || !d_lut256 || !d_clip_peak || !d_pcm_out || !d_workspace || N <= 0 || T <= 0)
     return fail(RFX_ERR_INVALID, "rfx_audio_from_image_u8: bad argument");
   const size_t need = rfx_audio_from_image_workspace_bytes(plan, N, stereo, T);
@@ -1634,7 +1717,7 @@ int rfx_audio_from_image_u8(const rfx_plan* plan, const uint8_t* d_img, int N, i
   void* rest = (char*)d_workspace + mel_bytes + wave_bytes;
   if (int rc = rfx_image_decode_u8(d_img, N, M, T, stereo, d_lut256, mel, stream)) return rc;
   // (a clip is one image: its channels share the SGD loss mean and the peak normalisation)
-  if (int rc = rfx_waveform_from_mel(plan, mel, B, T, C, seed, n_iter, momentum, wave, rest, workspace_bytes - mel_bytes - wave_bytes, stream)) return rc;
+  if (int rc = waveform_from_mel_impl(plan, mel, B, T, C, seed, n_iter, momentum, wave, rest, workspace_bytes - mel_bytes - wave_bytes, stream, opt)) return rc;
   return rfx_pcm16(wave, N, C, L, normalize, d_clip_peak, d_pcm_out, stream);
 }
 

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
 #pragma unroll
       for (int s = 0; s < RB; ++s) R[s] = gl_project(R[s], Sv[s]);
     } else {
-      const unsigned rng_key = rand_frame_key(a.seed, (unsigned long long)gf);  // the generic engine's stream
+      const unsigned rng_key = rand_frame_key(a.seed, a.frame_base + (unsigned long long)gf);  // the generic engine's stream
 #pragma unroll
       for (int s = 0; s < RB; ++s) {
         bool cj;

@@ -172,7 +172,7 @@ gen_gl_kernel(GenGlArgs a) {
       auto X = [&](int k) {
         cf ang;
         if (a.angles0) ang = a.angles0[base + k];
-        else ang = rand_unit_pair(rand_frame_key(a.seed, (unsigned long long)fr), k);
+        else ang = rand_unit_pair(rand_frame_key(a.seed, a.frame_base + (unsigned long long)fr), k);
         const float s = S[k];
         return cf{s * ang.re, s * ang.im};
       };

@@ -21,8 +21,11 @@
 // A workgroup walks a run of consecutive frames of one clip-channel, so that the 10-way overlap-add
 // of torch.istft is a register sliding window (thread n' owns sample n' of every hop block) and the
 // only cross-workgroup traffic is the 9-block halo at each end of a run.  Halo blocks are never
-// combined with atomics: run r writes its partial sums to the parity-(r&1) audio buffer and the
-// reader adds the two parity buffers, which keeps results bit-reproducible run to run.
+// combined with atomics: partial sums go to one of two parity audio buffers and the reader adds the
+// two.  Round 6: the parity is that of the frame's GROUP (kGlGroup = 16 consecutive frames of a row,
+// rfx_kernels.h) and the nine blocks across EVERY group boundary are split into two partial sums -
+// inside a run exactly as between two runs - so a clip's bits do not depend on where the launch's run
+// boundaries fall (on the batch the clip is converted in), and the per-frame form's fold reproduces them.
 #define RFX_PK 1  // packed fp32 butterflies (rfx_core.h)
 #include "rfx_frame.hip.h"
 #include "rfx_kernels.h"
@@ -81,10 +84,9 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   // (Until round 5 every clip was cut into ceil(slots / B) runs of its own: B = 65 launched 520 workgroups for 512 slots.)
   // Round 5, second step: the runs are NOT equal any more - the workgroups dispatched first (one per CU) get longer runs than
   // the ones that join them, by the ratio of the rates the pair was measured to run at (GlArgs::run_h / run_w1 / run_w2).
-  const long long nfr_all = (long long)g.B * g.T;  // < 2^31 (checked by the host)
-  const int gf_end = (int)gl_run_start((long long)blockIdx.x + 1, gridDim.x, nfr_all, g.run_h, g.run_w1, g.run_w2);
-  int gf = (int)gl_run_start(blockIdx.x, gridDim.x, nfr_all, g.run_h, g.run_w1, g.run_w2);
-  const int par = blockIdx.x & 1;
+  // Round 6: runs are whole groups of kGlGroup frames of a row (gl_run_start_frame), B T < 2^31 (checked by the host)
+  const int gf_end = (int)gl_run_start_frame((long long)blockIdx.x + 1, gridDim.x, g.B, g.T, g.run_h, g.run_w1, g.run_w2);
+  int gf = (int)gl_run_start_frame(blockIdx.x, gridDim.x, g.B, g.T, g.run_h, g.run_w1, g.run_w2);
   const int nblk = g.T - 1;  // hop blocks kept by istft's centre trim
 
   const size_t clip_slots = (size_t)g.T * kFrameStride;
@@ -117,8 +119,12 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   const rsrc_t in1 = make_rsrc(g.audio_in[1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t pv0 = make_rsrc(g.audio_prev[0] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t pv1 = make_rsrc(g.audio_prev[1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
-  const rsrc_t outA = make_rsrc(g.audio_out[par] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
-  const rsrc_t outB = make_rsrc(g.audio_out[par ^ 1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+  // the group of the frame being synthesised: [tg0, tg1], its partial sums go to the buffer of its parity (outA), explicit zeros
+  // for blocks no other group touches to the other one (outB); t0 is a group start (runs are whole groups)
+  int tg0 = t0, tg1 = min(g.T - 1, t0 + kGlGroup - 1);
+  const int par = (t0 / kGlGroup) & 1;
+  rsrc_t outA = make_rsrc(g.audio_out[par] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+  rsrc_t outB = make_rsrc(g.audio_out[par ^ 1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
 
   float acc[10];
 #pragma unroll
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   auto emit_scaled = [&](int blk, float scaled) {
     if (blk < 0 || blk >= nblk || !t.active) return;  // blk is wave-uniform
     const unsigned boff = (unsigned)blk * (kHop * 4u);
-    const bool full = (max(blk - 4, 0) >= t0) && (min(blk + 5, g.T - 1) <= t1);
+    const bool full = (max(blk - 4, 0) >= tg0) && (min(blk + 5, g.T - 1) <= tg1);
     st1(scaled, outA, npr4, boff);
     if (full) st1(0.f, outB, npr4, boff);
   };
@@ -181,8 +187,25 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #define RFX_STAMP(i) ((void)0)
 #endif
   for (int fr = t0; fr <= t1; ++fr) {
+    if ((fr & (kGlGroup - 1)) == 0 && fr != t0) {
+      // ---- group boundary inside the run (wave-uniform): what the end of a run does - the parked block (complete, of the old
+      // group) and the partial sums of the nine blocks across the cut leave for the old group's buffer; the new group starts its
+      // own chains from zero in the other one
+      emit_scaled(pend_blk, pend_val);
+      pend_blk = -1;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        emit(fr - kHalfHops + j, acc[j]);
+        acc[j] = 0.f;
+      }
+      tg0 = fr;
+      tg1 = min(g.T - 1, fr + kGlGroup - 1);
+      const rsrc_t tmp = outA;
+      outA = outB;
+      outB = tmp;
+    }
     const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
-    const unsigned rng_key = rand_frame_key(g.seed, (unsigned long long)clip * g.T + fr);
+    const unsigned rng_key = rand_frame_key(g.seed, g.frame_base + (unsigned long long)clip * g.T + fr);
 
     cf R[21];
     MagRegs mag;
@@ -378,7 +401,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_frame_kernel(GlFra
         const v2f w = ld2<RFX_STREAM_AUX>(init, q16 >> 1, 2u * foff + 20u * kQPad * 8u);
         R[20] = cf{w.x, w.y};
       } else {
-        const unsigned rng_key = rand_frame_key(g.seed, (unsigned long long)clip * g.T + fr);  // same stream as gl_iter_kernel
+        const unsigned rng_key = rand_frame_key(g.seed, g.frame_base + (unsigned long long)clip * g.T + fr);  // same stream as gl_iter_kernel
 #pragma unroll
         for (int kb = 0; kb < 21; ++kb) {
           bool cj;
@@ -398,23 +421,35 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_frame_kernel(GlFra
     if (t.active) {
       float* __restrict__ out = g.frames + (size_t)gf * kFramePitch + t.npr;
 #pragma unroll
-      for (int j = 0; j < 10; ++j) out[j * kHop] = y[j] * wv[j];
+      for (int j = 0; j < 10; ++j) out[j * kHop] = y[j];  // un-windowed: the fold forms the run kernel's fma chains
     }
     __syncthreads();  // the next frame's first LDS stores overwrite rows other waves are still gathering in P1'
   }
 }
 
-// x[clip][p] = out_scale[p] * sum over the frames t = blk-4 .. blk+5 that cover hop block blk = p / 441 (fixed order)
-__global__ void __launch_bounds__(256) gl_fold_kernel(const float* __restrict__ frames, const float* __restrict__ scale,
-                                                      float* __restrict__ out, int T, int L, size_t out_stride) {
+// x[clip][p]: overlap-add of the frames t = blk-4 .. blk+5 that cover hop block blk = p / 441, in the run kernel's arithmetic
+// (round 6, kGlGroup in rfx_kernels.h): an fma chain y w + acc in increasing t, split where a group boundary of the row falls
+// inside the block's frames, each side scaled by istft's normalisation, then added - the two parity buffers of gl_iter_kernel.
+// Both forms give a clip the same bits (tests/test_gpu_round6.py).
+__global__ void __launch_bounds__(256) gl_fold_kernel(const float* __restrict__ frames, const float* __restrict__ win,
+                                                      const float* __restrict__ scale, float* __restrict__ out, int T, int L, size_t out_stride) {
+#pragma clang fp contract(off)  // lo s + hi s below is two products and a sum, as in the run form (two stores and a load apart there)
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int clip = blockIdx.y;
   if (p >= L) return;
   const int blk = p / kHop, n = p - blk * kHop;
   const int tlo = max(blk - 4, 0), thi = min(blk + 5, T - 1);
-  float acc = 0.f;
-  for (int t = tlo; t <= thi; ++t) acc += frames[((size_t)clip * T + t) * kFramePitch + (blk - t + kHalfHops) * kHop + n];
-  out[(size_t)clip * out_stride + p] = acc * scale[p];
+  const int cut = thi & ~(kGlGroup - 1);  // first frame of the group that finishes the block
+  float lo = 0.f, hi = 0.f;
+  for (int t = tlo; t <= thi; ++t) {
+    const int j = blk - t + kHalfHops;
+    const float y = frames[((size_t)clip * T + t) * kFramePitch + j * kHop + n], w = win[j * kHop + n];
+    if (t < cut) lo = __fmaf_rn(y, w, lo);
+    else hi = __fmaf_rn(y, w, hi);
+  }
+  const float s = scale[p];
+  const float a = lo * s, b = hi * s;  // (HIP's __fmul_rn is a plain product the compiler may contract: the pragma above is what keeps these apart)
+  out[(size_t)clip * out_stride + p] = a + b;
 }
 
 hipError_t launch_gl_frame(int mode, const GlFrameArgs& g, int nblocks, hipStream_t stream) {
@@ -426,8 +461,8 @@ hipError_t launch_gl_frame(int mode, const GlFrameArgs& g, int nblocks, hipStrea
   }
   return hipGetLastError();
 }
-hipError_t launch_gl_fold(const float* frames, const float* scale, float* out, int B, int T, int L, size_t out_stride, hipStream_t stream) {
-  hipLaunchKernelGGL(gl_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, scale, out, T, L, out_stride);
+hipError_t launch_gl_fold(const float* frames, const float* win, const float* scale, float* out, int B, int T, int L, size_t out_stride, hipStream_t stream) {
+  hipLaunchKernelGGL(gl_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, win, scale, out, T, L, out_stride);
   return hipGetLastError();
 }
 size_t gl_frame_buffer_bytes(int B, int T) { return (size_t)B * T * kFramePitch * sizeof(float); }

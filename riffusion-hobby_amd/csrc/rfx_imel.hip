@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(kImelThreads) imel_kernel(ImelArgs a) {
   // ---- phase-B ownership: bins f = f_lo + tid + 256*j
   float spec[BPT], buf[BPT], w0[BPT], w1[BPT];
   int m0[BPT];
-  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
+  const unsigned rbase = rand_frame_key(a.seed, a.frame_base + (unsigned long long)frame);
 #pragma unroll
   for (int j = 0; j < BPT; ++j) {
     const int f = tb.f_lo + tid + kImelThreads * j;
@@ -433,7 +433,7 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
   const int clip = b / a.C;
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass (one frame per workgroup): this clip never stopped early
-  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
+  const unsigned rbase = rand_frame_key(a.seed, a.frame_base + (unsigned long long)frame);
 
   const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;           // long groups, counted down from the top
   const int gL = (tid < M - kImelThreads) ? tid : -1;             // short groups, counted up from 0
@@ -780,7 +780,7 @@ __device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, in
   const int clip = b / a.C;
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
-  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
+  const unsigned rbase = rand_frame_key(a.seed, a.frame_base + (unsigned long long)frame);
   int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;
   int gL = (tid < M - kImelThreads) ? tid : -1;
   if (gH >= 0 && gH < tb.line_from) {  // a long group that is not a line: into the (free: the plan checked) table-form slot
@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int clip = b / a.C;
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
-  const unsigned rbase = rand_frame_key(a.seed, (unsigned long long)frame);
+  const unsigned rbase = rand_frame_key(a.seed, a.frame_base + (unsigned long long)frame);
   for (int i = lane; i < a.max_iter; i += 64) part[i] = 0.f;
   const unsigned part_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address of part[0]
 

@@ -29,6 +29,7 @@ struct GlArgs {
   int run_h, run_w1, run_w2;
   float mom;                  // momentum / (1 + momentum)
   unsigned long long seed;
+  unsigned long long frame_base;  // rfx_call_options::row_base * T: frame (row, t) of this call draws its phases from key (seed, frame_base + row T + t)
   unsigned long long* timing;  // optional [nblocks][8] phase timers (RFX_TIMING builds only)
 #ifdef RFX_WGCLOCK
   int launch;                  // diagnostic build: index of this launch inside one rfx_griffinlim call (tools/probe_wgclock.py)
@@ -41,6 +42,25 @@ RFX_HD long long gl_run_start(long long b, long long runs, long long N, long lon
   const long long hb = b < h ? b : h, ht = runs < h ? runs : h;
   const long long Wb = w1 * hb + w2 * (b - hb), Wt = w1 * ht + w2 * (runs - ht);
   return N * Wb / Wt;
+}
+// Round 6: CANONICAL GROUPS.  torch.istft's overlap-add sums ten windowed frames per sample, and fp32 addition is not associative:
+// where two runs share a hop block, the block is the sum of two partial chains instead of one - so until round 5 a clip's audio
+// depended (in the last bit, then - Griffin-Lim amplifies it - in the last few PCM steps) on where the run boundaries of the
+// launch fell, i.e. on the batch it was converted in.  Now every row (clip-channel) is cut into the same groups of kGlGroup frames
+// whatever the batch is, EVERY group boundary splits the chains of the nine blocks across it (the run kernel flushes its partial
+// sums there exactly as it does at the end of a run, the fold kernel of the per-frame form sums the two sides separately), and
+// runs are whole groups.  A block's value is then s * chain(frames before the cut) + s * chain(frames from the cut on) for every
+// partition and both forms: a clip's bits are a function of the clip, its seed and its row index alone.  (>= 10 frames per group:
+// a block's ten frames span at most one cut.  16 divides the 64 frames per run of the headline shape, 64 tiles x 512 frames on 512
+// resident workgroups; the price is the granularity - a launch lasts as long as its longest run, a whole number of groups.)
+constexpr int kGlGroup = 16;
+RFX_HD int gl_groups_per_row(int T) { return (T + kGlGroup - 1) / kGlGroup; }
+// first frame (counted row after row) of run b of a launch over B rows of T frames: gl_run_start in units of groups
+RFX_HD long long gl_run_start_frame(long long b, long long runs, int B, int T, long long h, long long w1, long long w2) {
+  const long long ng = gl_groups_per_row(T);
+  const long long u = gl_run_start(b, runs, (long long)B * ng, h, w1, w2);
+  const long long row = u / ng;
+  return row * T + (u - row * ng) * kGlGroup;
 }
 
 hipError_t launch_gl_iter(int mode, const GlArgs& g, int nblocks, hipStream_t stream);
@@ -63,9 +83,10 @@ struct GlFrameArgs {
   int B, T, L, Lpad;
   float mom;
   unsigned long long seed;
+  unsigned long long frame_base;  // as GlArgs::frame_base
 };
 hipError_t launch_gl_frame(int mode, const GlFrameArgs& g, int nblocks, hipStream_t stream);
-hipError_t launch_gl_fold(const float* frames, const float* scale, float* out, int B, int T, int L, size_t out_stride, hipStream_t stream);
+hipError_t launch_gl_fold(const float* frames, const float* win, const float* scale, float* out, int B, int T, int L, size_t out_stride, hipStream_t stream);
 size_t gl_frame_buffer_bytes(int B, int T);
 
 // layout conversion between the reference's (B, n_stft, T) tensors and slot-major frames
@@ -206,6 +227,7 @@ struct ImelArgs {
   int max_iter;
   float lr, momentum;
   unsigned long long seed;
+  unsigned long long frame_base;  // rfx_call_options::row_base * T: frame f of this call draws its start from key (seed, frame_base + f)
 };
 hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream);  // variant: 0 best, 1 uniform groups, 2 general
 // scans loss_hist for the early-stop condition; it_stop[clip] = steps the reference would have run
@@ -244,6 +266,7 @@ struct GenGlArgs {
   float* frames;         // [B*T][win] windowed, scaled synthesis frames (gen_fold_kernel overlap-adds them)
   float mom;             // momentum / (1 + momentum)
   unsigned long long seed;
+  unsigned long long frame_base;  // as GlArgs::frame_base
   int B, T, L;
 };
 hipError_t prepare_generic_kernels(const GenGeom& g);
@@ -276,6 +299,7 @@ struct FamGlArgs {
   const float* win;      // [win]
   float mom;             // momentum / (1 + momentum)
   unsigned long long seed;
+  unsigned long long frame_base;  // as GlArgs::frame_base
   int B, T, L;
 };
 // forward STFT of the family geometries into the plan's plain layout (mode 0: |X| floats, mode 1: X complex), or (mode 2) fused

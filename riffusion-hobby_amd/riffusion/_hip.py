@@ -52,6 +52,19 @@ class RfxPlanOptions(ctypes.Structure):
                 ("frame_engine", ctypes.c_int32), ("plan_layout", ctypes.c_int32), ("imel_form", ctypes.c_int32)]
 
 
+class RfxCallOptions(ctypes.Structure):
+    """rfx_call_options of include/rfx.h (round 6): per-call options of the inverse entry points."""
+
+    _fields_ = [("struct_size", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("row_base", ctypes.c_uint64),
+                ("magnitude_hint", ctypes.c_float), ("reserved", ctypes.c_float)]
+
+
+def call_options(row_base: int = 0, magnitude_hint: float = 0.0) -> RfxCallOptions:
+    if row_base < 0:
+        raise ValueError("row_base must be >= 0")
+    return RfxCallOptions(ctypes.sizeof(RfxCallOptions), 0, int(row_base), float(magnitude_hint), 0.0)
+
+
 GL_FORMS = {"auto": 0, "runs": 1, "frames": 2}  # rfx_gl_form
 FRAME_ENGINES = {"auto": 0, "generic": 1}       # rfx_frame_engine
 PLAN_LAYOUTS = {"auto": 0, "generic": 1}        # rfx_plan_layout
@@ -96,6 +109,10 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p],
     ),
+    "rfx_griffinlim_ex": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p],
+    ),
     "rfx_unpack_magnitudes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rfx_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rfx_mel_from_waveform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -105,11 +122,17 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_uint64, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
+    "rfx_inverse_mel_ex": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_uint64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p],
+    ),
     "rfx_image_decode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rfx_image_encode_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rfx_audio_from_image_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "rfx_audio_from_image_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_uint64, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rfx_audio_from_image_u8_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_uint64, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "rfx_waveform_from_mel_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "rfx_waveform_from_mel_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_uint64, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "rfx_waveform_from_mel": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_uint64, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rfx_image_from_waveform_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "rfx_image_from_waveform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -214,6 +237,81 @@ def mel_filterbank(
     return fb.to(torch.float32).contiguous()
 
 
+class WorkspaceArena:
+    """
+    Reusable device workspaces of ONE plan (round 6).  Every C entry point takes a caller-provided scratch buffer (1.7 GB for
+    64 mono tiles); until round 5 each Python call asked torch's caching allocator for a fresh one, and the allocator - which
+    splits a freed 1.7 GB block as soon as a smaller request comes by - answered one call in twenty with a 20 ms hipMalloc.
+    The arena keeps the buffers instead:
+
+    * `take(nbytes, stream)` CHECKS OUT an idle buffer of at least `nbytes` that was last used on the same HIP stream (kernels
+      of consecutive calls on one stream are ordered, so the hand-over needs no event), or allocates one - grow-only: a buffer
+      that is too small is dropped in favour of the bigger one, sizes are rounded up to 32 MiB;
+    * `give(buf, stream)` returns it when the call has QUEUED its kernels.
+    A buffer that is checked out belongs to one host call: two threads of a pool that share a converter - and torch's default
+    stream - (reference cli.py:172-204) get two buffers.  The lock guards the free lists only (microseconds); allocation happens
+    outside it.  At most `max_idle` idle buffers are kept per plan (least recently used dropped first); `clear()` / the plan's
+    `close()` release them.  The buffers are torch tensors, so `torch.cuda.memory_stats()` sees them.
+    """
+
+    GRANULE = 32 << 20
+
+    def __init__(self, device: torch.device, max_idle: int = 4):
+        self.device, self.max_idle = device, max_idle
+        self._lock = threading.Lock()
+        self._idle: "collections.OrderedDict[int, T.Tuple[int, torch.Tensor]]" = collections.OrderedDict()  # id -> (stream, buffer), LRU first
+        self.allocations = 0  # buffers ever allocated (tests: steady state allocates nothing)
+
+    def take(self, nbytes: int, stream: int) -> torch.Tensor:
+        dropped = None
+        with self._lock:
+            best = None
+            for key, (st, buf) in self._idle.items():
+                if st == stream and buf.numel() >= nbytes and (best is None or buf.numel() < self._idle[best][1].numel()):
+                    best = key
+            if best is not None:
+                return self._idle.pop(best)[1]
+            for key, (st, buf) in self._idle.items():  # grow: the too-small buffer of this stream makes room for its successor
+                if st == stream:
+                    dropped = self._idle.pop(key)[1]
+                    break
+            self.allocations += 1
+        del dropped  # back to torch's allocator (it was allocated and used on `stream` only: stream-ordered reuse is safe)
+        size = max(self.GRANULE, -(-int(nbytes) // self.GRANULE) * self.GRANULE)
+        return torch.empty(size, dtype=torch.uint8, device=self.device)
+
+    def give(self, buf: torch.Tensor, stream: int) -> None:
+        with self._lock:
+            self._idle[id(buf)] = (stream, buf)
+            while len(self._idle) > self.max_idle:
+                self._idle.popitem(last=False)
+
+    def clear(self) -> None:
+        with self._lock:
+            self._idle.clear()
+
+    def idle_bytes(self) -> int:
+        with self._lock:
+            return sum(buf.numel() for _, buf in self._idle.values())
+
+
+class _Borrowed:
+    """`with plan._workspace(n) as ws:` - a checked-out arena buffer, returned when the call's kernels have been queued."""
+
+    __slots__ = ("arena", "stream", "buf")
+
+    def __init__(self, arena: WorkspaceArena, nbytes: int, stream: int):
+        self.arena, self.stream = arena, stream
+        self.buf = arena.take(nbytes, stream)
+
+    def __enter__(self) -> torch.Tensor:
+        return self.buf
+
+    def __exit__(self, *exc: T.Any) -> bool:
+        self.arena.give(self.buf, self.stream)
+        return False
+
+
 class Plan:
     """Owns one rfx_plan (device constants for one parameter set on one device)."""
 
@@ -257,9 +355,38 @@ class Plan:
         self.frame_stride = self.lib.rfx_plan_frame_stride(self.handle)
         self.generic = bool(self.lib.rfx_plan_is_generic(self.handle))
         self.griffinlim_engine = GL_ENGINE_NAMES[self.lib.rfx_plan_griffinlim_engine(self.handle)]
+        self.arena = WorkspaceArena(device, max_idle=max(1, int(os.environ.get("RFX_ARENA_IDLE", "4"))))
+        self._consts: "collections.OrderedDict[T.Any, torch.Tensor]" = collections.OrderedDict()
+        self._consts_lock = threading.Lock()
+
+    def _workspace(self, nbytes: int) -> _Borrowed:
+        """A scratch buffer of at least `nbytes` from the plan's arena for the duration of one call on the current stream."""
+        return _Borrowed(self.arena, nbytes, self._stream())
+
+    def release_workspaces(self) -> None:
+        """Hands the idle scratch buffers back to torch's allocator (they are re-made on demand)."""
+        self.arena.clear()
+
+    def device_constant(self, key: T.Any, build: T.Callable[[], T.Any]) -> torch.Tensor:
+        """Small host-built tables (decode LUT, encoder thresholds) uploaded ONCE per plan and key: an upload from pageable
+        memory per call is a synchronous copy - the host would wait for the kernels queued before it, call after call."""
+        with self._consts_lock:
+            t = self._consts.get(key)
+            if t is not None:
+                self._consts.move_to_end(key)
+                return t
+        t = torch.as_tensor(build()).to(self.device)
+        with self._consts_lock:
+            self._consts[key] = t
+            while len(self._consts) > 64:
+                self._consts.popitem(last=False)
+        return t
 
     def close(self) -> None:
         """Releases the plan's device memory now (it is released anyway when the last reference goes)."""
+        arena = getattr(self, "arena", None)
+        if arena is not None:
+            arena.clear()
         handle, self.handle = getattr(self, "handle", None), None
         if handle:
             self.lib.rfx_plan_destroy(handle)
@@ -338,7 +465,12 @@ class Plan:
         seed: int = 0,
         workspace: T.Optional[torch.Tensor] = None,
         launch_ms: T.Optional[T.Any] = None,
+        row_base: int = 0,
+        magnitude_hint: float = 0.0,
     ) -> torch.Tensor:
+        """GriffinLim on magnitudes in slot layout -> (B, samples).  `row_base`: index of the call's first row in the caller's
+        whole batch (the random phases of row r are drawn from (seed, row_base + r): chunked and sharded batches get the starts
+        of the single call); `magnitude_hint`: an upper bound of the magnitudes if the caller knows one (rfx_call_options)."""
         mag_slots = self._chk(mag_slots, torch.float32)
         if angles0_slots is not None:
             angles0_slots = self._chk(angles0_slots, torch.complex64)
@@ -347,30 +479,13 @@ class Plan:
         need = self.lib.rfx_griffinlim_workspace_bytes(self.handle, B, Tn)
         if workspace is not None:
             workspace = self._chk(workspace)
-        if workspace is None or workspace.numel() < need:
-            workspace = torch.empty(need, dtype=torch.uint8, device=mag_slots.device)
+        if workspace is None or workspace.numel() < need:  # no (or too small a) caller-owned workspace: the plan's arena
+            with self._workspace(need) as ws:
+                return self.griffinlim(mag_slots, B, Tn, n_iter, momentum, angles0_slots, seed, ws, launch_ms, row_base, magnitude_hint)
         out = torch.empty((B, self.lib.rfx_griffinlim_output_samples(self.handle, Tn)), dtype=torch.float32, device=mag_slots.device)
-        if launch_ms is not None:  # ctypes float array of n_iter + 1 entries, filled after a stream sync
-            check(
-                self.lib.rfx_griffinlim_timed(
-                    self.handle,
-                    mag_slots.data_ptr(),
-                    angles0_slots.data_ptr() if angles0_slots is not None else None,
-                    seed & 0xFFFFFFFFFFFFFFFF,
-                    B,
-                    Tn,
-                    n_iter,
-                    momentum,
-                    out.data_ptr(),
-                    workspace.data_ptr(),
-                    workspace.numel(),
-                    self._stream(),
-                    ctypes.cast(launch_ms, c_void_p),
-                )
-            )
-            return out
+        opt = call_options(row_base, magnitude_hint)
         check(
-            self.lib.rfx_griffinlim(
+            self.lib.rfx_griffinlim_ex(
                 self.handle,
                 mag_slots.data_ptr(),
                 angles0_slots.data_ptr() if angles0_slots is not None else None,
@@ -383,10 +498,11 @@ class Plan:
                 workspace.data_ptr(),
                 workspace.numel(),
                 self._stream(),
+                ctypes.byref(opt),
+                ctypes.cast(launch_ms, c_void_p) if launch_ms is not None else None,  # ctypes float array of n_iter + 1 entries, filled after a stream sync
             )
         )
         return out
-
 
     def unpack_magnitudes(self, slots: torch.Tensor, B: int, Tn: int) -> torch.Tensor:
         slots = self._chk(slots, torch.float32)
@@ -405,13 +521,13 @@ class Plan:
             )
         Tn = self.lib.rfx_stft_frames(self.handle, Lw)
         need = self.lib.rfx_mel_workspace_bytes(self.handle, B, Lw)
-        ws = torch.empty(need, dtype=torch.uint8, device=wave.device)
         out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=wave.device)
-        check(
-            self.lib.rfx_mel_from_waveform(
-                self.handle, wave.data_ptr(), B, Lw, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()
+        with self._workspace(need) as ws:
+            check(
+                self.lib.rfx_mel_from_waveform(
+                    self.handle, wave.data_ptr(), B, Lw, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()
+                )
             )
-        )
         return out
 
     def mel_scale(self, lin_bft: torch.Tensor) -> torch.Tensor:
@@ -420,9 +536,9 @@ class Plan:
         B, F, Tn = lin_bft.shape
         if F != self.n_stft:
             raise ValueError(f"expected {self.n_stft} linear bins, got {F}")
-        ws = torch.empty(self.lib.rfx_mel_scale_workspace_bytes(self.handle, B, Tn), dtype=torch.uint8, device=lin_bft.device)
         out = torch.empty((B, self.n_mels, Tn), dtype=torch.float32, device=lin_bft.device)
-        check(self.lib.rfx_mel_scale(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        with self._workspace(self.lib.rfx_mel_scale_workspace_bytes(self.handle, B, Tn)) as ws:
+            check(self.lib.rfx_mel_scale(self.handle, lin_bft.data_ptr(), B, Tn, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
     def inverse_mel(
@@ -431,8 +547,11 @@ class Plan:
         channels_per_clip: int,
         spec0: T.Optional[torch.Tensor] = None,
         seed: int = 0,
+        row_base: int = 0,
+        magnitude_hint: float = 0.0,
     ) -> torch.Tensor:
-        """InverseMelScale (SGD): (B, n_mels, T) -> linear magnitudes in slot layout (B*T, stride)."""
+        """InverseMelScale (SGD): (B, n_mels, T) -> linear magnitudes in slot layout (B*T, stride).  `row_base`,
+        `magnitude_hint`: as in `griffinlim` (row_base must be a multiple of channels_per_clip: clips are not split)."""
         mel = self._chk(mel, torch.float32)
         B, M, Tn = mel.shape
         if M != self.n_mels:
@@ -442,23 +561,25 @@ class Plan:
             if tuple(spec0.shape) != (B, Tn, self.n_stft):
                 raise ValueError(f"spec0 must be (B, T, n_stft) = {(B, Tn, self.n_stft)}, got {tuple(spec0.shape)}")
         need = self.lib.rfx_inverse_mel_workspace_bytes(self.handle, B, Tn)
-        ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
         out = torch.empty((B * Tn, self.frame_stride), dtype=torch.float32, device=mel.device)
-        check(
-            self.lib.rfx_inverse_mel(
-                self.handle,
-                mel.data_ptr(),
-                B,
-                Tn,
-                channels_per_clip,
-                spec0.data_ptr() if spec0 is not None else None,
-                seed & 0xFFFFFFFFFFFFFFFF,
-                out.data_ptr(),
-                ws.data_ptr(),
-                ws.numel(),
-                self._stream(),
+        opt = call_options(row_base, magnitude_hint)
+        with self._workspace(need) as ws:
+            check(
+                self.lib.rfx_inverse_mel_ex(
+                    self.handle,
+                    mel.data_ptr(),
+                    B,
+                    Tn,
+                    channels_per_clip,
+                    spec0.data_ptr() if spec0 is not None else None,
+                    seed & 0xFFFFFFFFFFFFFFFF,
+                    out.data_ptr(),
+                    ws.data_ptr(),
+                    ws.numel(),
+                    self._stream(),
+                    ctypes.byref(opt),
+                )
             )
-        )
         return out
 
     # ---- codecs (no plan state needed, kept here for one binding site) -------------------------
@@ -488,27 +609,33 @@ class Plan:
         check(self.lib.rfx_image_encode_u8(mel.data_ptr(), N, M, Tn, int(stereo), thresholds.data_ptr(), mx.data_ptr(), img.data_ptr(), self._stream()))
         return img, mx
 
-    def waveform_from_mel(self, mel: torch.Tensor, channels_per_clip: int, n_iter: int, momentum: float = 0.99, seed: int = 0) -> torch.Tensor:
+    def waveform_from_mel(self, mel: torch.Tensor, channels_per_clip: int, n_iter: int, momentum: float = 0.99, seed: int = 0,
+                          row_base: int = 0, magnitude_hint: float = 0.0) -> torch.Tensor:
         """spectrogram_converter.py:187-204 in one call: (B, n_mels, T) -> (B, hop * (T - 1)); `inverse_mel` (seed) + `griffinlim`
         (seed + 1), same bits, the linear magnitudes stay in the workspace."""
         mel = self._chk(mel, torch.float32)
         B, M, Tn = mel.shape
         if M != self.n_mels:
             raise ValueError(f"Expected an input with {self.n_mels} mel bins. Found: {M}")  # torchaudio's message
-        ws = torch.empty(self.lib.rfx_waveform_from_mel_workspace_bytes(self.handle, B, Tn), dtype=torch.uint8, device=mel.device)
         out = torch.empty((B, self.lib.rfx_griffinlim_output_samples(self.handle, Tn)), dtype=torch.float32, device=mel.device)
-        check(self.lib.rfx_waveform_from_mel(self.handle, mel.data_ptr(), B, Tn, channels_per_clip, seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
-                                             out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        opt = call_options(row_base, magnitude_hint)
+        with self._workspace(self.lib.rfx_waveform_from_mel_workspace_bytes(self.handle, B, Tn)) as ws:
+            check(self.lib.rfx_waveform_from_mel_ex(self.handle, mel.data_ptr(), B, Tn, channels_per_clip, seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
+                                                    out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(), ctypes.byref(opt)))
         return out
 
     def audio_from_image_workspace(self, N: int, stereo: bool, Tn: int) -> torch.Tensor:
-        """A workspace for `audio_from_image` calls of up to N images of Tn frames (a caller that converts chunk after chunk keeps one)."""
+        """A caller-owned workspace for `audio_from_image` calls of up to N images of Tn frames (optional since round 6: without
+        one the call borrows a buffer from the plan's arena)."""
         return torch.empty(self.lib.rfx_audio_from_image_workspace_bytes(self.handle, N, int(stereo), Tn), dtype=torch.uint8, device=self.device)
 
     def audio_from_image(self, img: torch.Tensor, stereo: bool, lut: torch.Tensor, n_iter: int, momentum: float = 0.99, seed: int = 0,
-                         normalize: bool = True, out: T.Optional[torch.Tensor] = None, workspace: T.Optional[torch.Tensor] = None):
+                         normalize: bool = True, out: T.Optional[torch.Tensor] = None, workspace: T.Optional[torch.Tensor] = None,
+                         clip_base: int = 0, magnitude_hint: float = 0.0):
         """spectrogram_image_converter.py:54-91 on the device in one call: (N, n_mels, T, 3) uint8 -> ((N, L, C) int16, per-clip peak (N,));
-        `image_decode` + `waveform_from_mel` (clips of C rows) + `pcm16`, same bytes.  `out` as in `pcm16`."""
+        `image_decode` + `waveform_from_mel` (clips of C rows) + `pcm16`, same bytes.  `out` as in `pcm16`.  `clip_base`: index of
+        the call's first image in the caller's whole batch (row_base = clip_base * C); `magnitude_hint`: the image path's
+        max_value (the largest entry of `lut`)."""
         if img.dtype != torch.uint8 or img.dim() != 4:
             raise ValueError("expected (N, H, W, 3) uint8 images")
         img = self._chk(img)
@@ -528,9 +655,12 @@ class Plan:
         need = self.lib.rfx_audio_from_image_workspace_bytes(self.handle, N, int(stereo), W)
         ws = self._chk(workspace) if workspace is not None else None
         if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.uint8, device=img.device)
-        check(self.lib.rfx_audio_from_image_u8(self.handle, img.data_ptr(), N, W, int(stereo), lut.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
-                                               int(normalize), peak.data_ptr(), pcm.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+            with self._workspace(need) as borrowed:
+                return self.audio_from_image(img, stereo, lut, n_iter, momentum, seed, normalize, out=pcm, workspace=borrowed,
+                                             clip_base=clip_base, magnitude_hint=magnitude_hint)
+        opt = call_options(clip_base * C, magnitude_hint)
+        check(self.lib.rfx_audio_from_image_u8_ex(self.handle, img.data_ptr(), N, W, int(stereo), lut.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
+                                                  int(normalize), peak.data_ptr(), pcm.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(), ctypes.byref(opt)))
         return pcm, peak
 
     def image_from_waveform(self, wave: torch.Tensor, stereo: bool, thresholds: torch.Tensor):
@@ -549,11 +679,11 @@ class Plan:
             )
         N = NC // C
         Tn = self.lib.rfx_stft_frames(self.handle, Lw)
-        ws = torch.empty(self.lib.rfx_image_from_waveform_workspace_bytes(self.handle, N, int(stereo), Lw), dtype=torch.uint8, device=wave.device)
         img = torch.empty((N, self.n_mels, Tn, 3), dtype=torch.uint8, device=wave.device)
         mx = torch.empty((N,), dtype=torch.float32, device=wave.device)
-        check(self.lib.rfx_image_from_waveform(self.handle, wave.data_ptr(), N, int(stereo), Lw, thresholds.data_ptr(), mx.data_ptr(),
-                                               img.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        with self._workspace(self.lib.rfx_image_from_waveform_workspace_bytes(self.handle, N, int(stereo), Lw)) as ws:
+            check(self.lib.rfx_image_from_waveform(self.handle, wave.data_ptr(), N, int(stereo), Lw, thresholds.data_ptr(), mx.data_ptr(),
+                                                   img.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return img, mx
 
     def pcm16(self, wave: torch.Tensor, channels: int, normalize: bool = True, out: T.Optional[torch.Tensor] = None):

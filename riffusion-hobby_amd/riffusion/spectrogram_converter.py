@@ -14,8 +14,8 @@ builds (:47-99) are replaced by callables that run hand-written HIP kernels thro
 The two torch-level methods fuse these pairs so the (B, n_stft, T) intermediates of the reference are
 never materialised; the standalone callables exist for code that pokes at the members directly.
 Every call is re-entrant: the converter holds immutable constants only (plans are cached per
-(params, device)), workspaces are per call - the reference shares one converter across a thread pool
-(cli.py:172-204).  There is no CPU implementation: on a machine without a GPU the constructor still
+(params, device)), workspaces are checked out of the plan's arena per call (`_hip.WorkspaceArena`: two
+threads never share one) - the reference shares one converter across a thread pool (cli.py:172-204).  There is no CPU implementation: on a machine without a GPU the constructor still
 mirrors the reference's fallback warning, and any compute call raises.
 """
 import typing as T
@@ -168,7 +168,7 @@ class SpectrogramConverter:
 
     def _waveform_from_mel(self, plan: T.Any, amplitudes_mel: torch.Tensor, *, spec0: T.Optional[torch.Tensor] = None,
                            angles0: T.Optional[torch.Tensor] = None, seed: T.Optional[int] = None,
-                           channels_per_clip: T.Optional[int] = None) -> torch.Tensor:
+                           channels_per_clip: T.Optional[int] = None, row_base: int = 0, magnitude_hint: float = 0.0) -> torch.Tensor:
         """`waveform_from_mel_amplitudes` on a plan the caller already holds (the batch entry points fetch it once per call,
         not once per chunk and stage: a fetch is a lock and a dictionary lookup, and after an eviction a rebuild)."""
         mel = amplitudes_mel.to(self.device)
@@ -176,8 +176,9 @@ class SpectrogramConverter:
         cpc = B if channels_per_clip is None else channels_per_clip
         s = self._seed(seed)
         if spec0 is None and angles0 is None:  # the production path: one call (rfx_waveform_from_mel), same bits as the two below
-            return plan.waveform_from_mel(mel, cpc, self.p.num_griffin_lim_iters, 0.99, seed=s)
+            return plan.waveform_from_mel(mel, cpc, self.p.num_griffin_lim_iters, 0.99, seed=s, row_base=row_base, magnitude_hint=magnitude_hint)
         spec0 = spec0.to(self.device) if spec0 is not None else None
-        lin_slots = plan.inverse_mel(mel, cpc, spec0=spec0, seed=s)
+        lin_slots = plan.inverse_mel(mel, cpc, spec0=spec0, seed=s, row_base=row_base, magnitude_hint=magnitude_hint)
         a0 = plan.pack_complex(angles0.to(self.device)) if angles0 is not None else None
-        return plan.griffinlim(lin_slots, B, Tn, self.p.num_griffin_lim_iters, 0.99, angles0_slots=a0, seed=s + 1)
+        return plan.griffinlim(lin_slots, B, Tn, self.p.num_griffin_lim_iters, 0.99, angles0_slots=a0, seed=s + 1, row_base=row_base,
+                               magnitude_hint=magnitude_hint)

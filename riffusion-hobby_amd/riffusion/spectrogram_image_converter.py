@@ -74,7 +74,8 @@ class SpectrogramImageConverter:
         N, C, L = waveforms.shape
         if C != (2 if self.p.stereo else 1):
             raise ValueError(f"expected {2 if self.p.stereo else 1} channel(s), got {C}")
-        thr = torch.from_numpy(image_util.encode_thresholds(float(self.p.power_for_image))).to(conv.device)
+        power = float(self.p.power_for_image)
+        thr = plan.device_constant(("encode_thresholds", power), lambda: image_util.encode_thresholds(power))
         # one call (rfx_image_from_waveform): the mel amplitudes go from the forward kernel to the encoder without the (N*C, M, T) tensor
         img, mx = plan.image_from_waveform(waveforms.reshape(N * C, L).to(conv.device, torch.float32), self.p.stereo, thr)
         img_np, mx_np = img.cpu().numpy(), mx.cpu().numpy()
@@ -132,8 +133,11 @@ class SpectrogramImageConverter:
                     every rank receives and copies all N clips, so it does not scale; ask for it explicitly).
         Host results are staged through pinned memory; without a collective each chunk's device-to-host
         copy runs on a side stream while the next chunk computes (`batch_shard.ChunkSink`).
-        Like the reference, the two random initialisations are not reproducible across different
-        shardings (each call draws its own streams from `seed`).
+        With a `seed`, a clip's audio is a function of (the clip, the seed, the clip's index in `images_u8`) alone - the same
+        bytes whatever `tiles_per_call` is and however many ranks share the batch (round 6: the random starts are keyed by
+        the clip's global row, and nothing in the kernels' arithmetic depends on the batch a clip travels in).  Without one the
+        seed is drawn from torch's global generator, like the reference's random starts (in a group: pass a seed, or seed
+        torch identically on every rank).
         """
         from riffusion import batch_shard
 
@@ -162,7 +166,10 @@ class SpectrogramImageConverter:
         C = 2 if self.p.stereo else 1
         L = plan.lib.rfx_griffinlim_output_samples(plan.handle, int(imgs.shape[2]))
         base_seed = conv._seed(seed)
-        lut = torch.from_numpy(image_util.decode_lut(float(self.p.power_for_image), float(max_value))).to(plan.device)
+        power, max_value = float(self.p.power_for_image), float(max_value)
+        if not (max_value > 0.0 and max_value < float("inf")):
+            raise ValueError(f"max_value must be a positive finite number, got {max_value}")
+        lut = plan.device_constant(("decode_lut", power, max_value), lambda: image_util.decode_lut(power, max_value))
         row_shape, dtype = ((C, L), torch.float32) if return_waveform else ((L, C), torch.int16)
 
         pg = None if group is None else batch_shard._resolve_group(group)
@@ -174,17 +181,16 @@ class SpectrogramImageConverter:
             sink = batch_shard.ChunkSink(hi - lo, row_shape, dtype, plan.device, to_host=not (collective or return_device))
             bounds = [(a, min(hi, a + tiles_per_call)) for a in range(lo, hi, tiles_per_call)]  # bounded working set: |S| alone is 19 MB per tile-channel
             source = batch_shard.ChunkSource(imgs, bounds, plan.device)
-            # one workspace for all chunks of the call (1.7 GB for 64 mono tiles: not a fresh request to the allocator per chunk)
-            ws = None if return_waveform or not bounds else plan.audio_from_image_workspace(max(b - a for a, b in bounds), self.p.stereo, int(imgs.shape[2]))
+            # (the scratch space - 1.7 GB for 64 mono tiles - comes from the plan's arena: the same buffer chunk after chunk and call after call)
             for i, (a, b) in enumerate(bounds):
                 if return_waveform:
                     mel = plan.image_decode(source.get(i), self.p.stereo, lut)
-                    wave = conv._waveform_from_mel(plan, mel, seed=base_seed + 2 * a, channels_per_clip=C)
+                    wave = conv._waveform_from_mel(plan, mel, seed=base_seed, channels_per_clip=C, row_base=a * C, magnitude_hint=max_value)
                     out = wave.reshape(b - a, C, -1)
-                else:  # uint8 tiles -> int16 PCM in one call (rfx_audio_from_image_u8), same bytes as the three calls above + pcm16
+                else:  # uint8 tiles -> int16 PCM in one call (rfx_audio_from_image_u8_ex), same bytes as the three calls above + pcm16
                     dst = sink.rows(a - lo, b - lo)  # device sink: the PCM kernel writes the batch rows in place
-                    out = plan.audio_from_image(source.get(i), self.p.stereo, lut, self.p.num_griffin_lim_iters, 0.99, seed=base_seed + 2 * a,
-                                                normalize=True, out=dst, workspace=ws)[0]
+                    out = plan.audio_from_image(source.get(i), self.p.stereo, lut, self.p.num_griffin_lim_iters, 0.99, seed=base_seed,
+                                                normalize=True, out=dst, clip_base=a, magnitude_hint=max_value)[0]
                 # this chunk's kernels are queued: the host stages and uploads the next chunk underneath them
                 source.prefetch(i + 1)
                 sink.put(a - lo, b - lo, out)
@@ -194,10 +200,12 @@ class SpectrogramImageConverter:
         if return_device:
             if range_ok is not None:
                 # nothing on this path ever synchronises, so the deferred check cannot raise here: out-of-range (or NaN) input
-                # yields SILENCE instead of garbage audio (one fused multiply on the device, no host sync), and the flag travels
-                # with the result for a caller that wants to look: `result.range_ok` (0-dim bool tensor on the device)
-                result = result * range_ok.to(result.dtype)
-                result.range_ok = range_ok
+                # yields SILENCE instead of garbage audio (one in-place multiply on the device, no host sync, no copy of the batch)
+                result.mul_(range_ok.to(result.dtype))
+            # the flag travels with the result for a caller that wants to look: `result.range_ok`, a 0-dim bool tensor on the device
+            # (True when nothing was checked: uint8 input, validate=False, or a check that already ran on the host).  It is a plain
+            # attribute: slicing / .to() / a gather make a new tensor without it - read it from the tensor this call returned.
+            result.range_ok = range_ok if range_ok is not None else torch.ones((), dtype=torch.bool, device=result.device)
             return result
         if result.is_cuda:
             host = torch.empty(result.shape, dtype=result.dtype, pin_memory=True)  # gathered batch: one pinned copy

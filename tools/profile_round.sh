@@ -34,16 +34,12 @@ try:
     rev = open("$R/.git_rev").read().strip()   # written by tools/gpu.sh: the pushed snapshot has no .git
 except Exception:
     rev = "not recorded"
-def src_sha(files):  # bench.py::kernel_source_fingerprint: which kernel sources these counters belong to
-    import hashlib
-    h = hashlib.sha1()
-    for name in files:
-        try:
-            h.update(open("$R/riffusion-hobby_amd/csrc/" + name, "rb").read())
-        except OSError:
-            h.update(b"?")
-    return h.hexdigest()[:12]
-SRC = {"gl_iter_pmc.json": ("rfx_gl.hip", "rfx_core.h", "rfx_frame.hip.h"), "forward_pmc.json": ("rfx_stft.hip", "rfx_core.h", "rfx_frame.hip.h")}
+import sys
+sys.path.insert(0, "$R")
+import bench  # kernel_source_fingerprint: comment- and whitespace-insensitive (round 6)
+def src_sha(files):
+    return bench.kernel_source_fingerprint(tuple(files))
+SRC = {"gl_iter_pmc.json": ("rfx_gl.hip", "rfx_core.h", "rfx_frame.hip.h", "rfx_kernels.h"), "forward_pmc.json": bench.FORWARD_KERNEL_SOURCES}
 for key, fname in (("gl_iter_kernel<2>", "gl_iter_pmc.json"), ("stft_mel2_kernel", "forward_pmc.json")):
     res = {}
     for k in tables["FETCH_SIZE"]:
