@@ -143,7 +143,29 @@ int rfx_stft_frames(const rfx_plan* plan, int Lw);
  *   in one call, in chunks (row_base = rows before the chunk) or sharded over the GPUs of a node gives the same audio for every clip,
  *   bit for bit: nothing else in a clip's arithmetic depends on the batch it travels in (csrc/rfx_kernels.h: kGlGroup).
  *   Must be a multiple of channels_per_clip where the entry point has one.
- * magnitude_hint: see "Numeric range" below; 0 = not given. */
+ * magnitude_hint: see "Numeric range" below; 0 = not given.
+ *
+ * Numeric range of the inverse entry points (rfx_inverse_mel, rfx_griffinlim, rfx_waveform_from_mel, rfx_audio_from_image_u8
+ * and their *_ex forms).  The reference scales a decoded image by a caller-chosen `max_value` (image_util.py:59-108, default 30e6
+ * at spectrogram_image_converter.py:69) and runs torchaudio in plain float32; so does this library, with two internal powers of
+ * two that keep its fast paths inside float32 whatever the units are:
+ *   - InverseMelScale holds the SGD state of a clip times 2^-e, e = max(k + 35, 30) for a largest mel amplitude in [2^(k-1), 2^k)
+ *     (e = 60 at max_value 30e6): the `clamp(min=0)` of every step is then the output clamp of the FMA that makes it;
+ *   - Griffin-Lim analyses a row's signal times 2^-j, j = k' - 26 for a largest magnitude in [2^(k'-1), 2^k') (j = 0 at 30e6),
+ *     so that |a|^2 in a / (|a| + 1e-16) can neither overflow nor vanish.
+ * Both commute with every float32 rounding of the linear steps: the results are those of the unscaled arithmetic, and an input
+ * times 2^n gives the output times 2^n bit for bit (tests/test_gpu_round6_range.py).  The exponents are taken PER CLIP / PER ROW from
+ * the data by one small reduction launch - or from magnitude_hint > 0, an upper bound of the call's magnitudes in the input's
+ * units (the image path passes max_value), without reading the data.  A hint below the data is the caller's error: magnitudes
+ * above 2^35 x hint saturate the SGD state.
+ * Supported, and held against the oracle at 1e-6, 1, 30e6, 1e12, 1e20 (Griffin-Lim also 1e30): magnitudes from 0 up to 2^91 = 2.5e27
+ * (InverseMelScale; above it the headroom of the clamp shrinks, at 2^126 it is gone) and 1e33 (Griffin-Lim: float32 itself ends
+ * where 8821 bins of that size add up).  Not supported: NaN / Inf magnitudes (garbage in, garbage out, as in the reference).
+ * Where the reference itself stops being scale-free, this library follows the reference, not the scale: its stopping rule is
+ * absolute (loss < 1e-5, |change| < 1e-8: tiny spectrograms stop after one step - reproduced), the bins no filter reaches keep
+ * their U[0,1) start whatever max_value is (reproduced), and below |a| = 1e-8 in the input's units the `+ 1e-16` guard becomes
+ * visible: there this library's guard, rsq(|a|^2 + 1e-32), differs from the reference's 1 / (|a| + 1e-16) by up to a factor of
+ * two in the length of the phase factor (never in its direction; exactly 0 for a = 0 in both). */
 typedef struct {
   uint32_t struct_size;
   uint32_t flags;           /* must be 0 */

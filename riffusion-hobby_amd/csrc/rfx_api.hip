@@ -966,6 +966,9 @@ int rfx_griffinlim_form(const rfx_plan* plan, int B, int T) {
   return gl_use_latency_mode(plan, B, T) ? RFX_GL_FORM_FRAMES : RFX_GL_FORM_RUNS;
 }
 
+// [B][2] floats of scales + [B] key words (launch_range_scale)
+static size_t range_table_bytes(int B) { return align_up((size_t)B * 3 * sizeof(float), 256); }
+
 static void gl_layout(const rfx_plan* plan, int B, int T, size_t& off_audio, size_t& off_scale, size_t& off_frames, size_t& total, int& Lpad) {
   const int L = kHop * (T - 1);
   Lpad = (int)align_up((size_t)L, 64);
@@ -976,6 +979,7 @@ static void gl_layout(const rfx_plan* plan, int B, int T, size_t& off_audio, siz
   o += align_up((size_t)Lpad * sizeof(float), 256);
   off_frames = o;
   if (gl_use_latency_mode(plan, B, T)) o += align_up(gl_frame_buffer_bytes(B, T), 256);
+  o += range_table_bytes(B);  // the call's own row-scale table (GlArgs::row_scale), at total - range_table_bytes(B)
   total = o;
 }
 
@@ -994,6 +998,7 @@ static void gen_gl_layout(const rfx_plan* plan, int B, int T, size_t& off_frames
   off_audio = o;
   o += align_up((3 * (size_t)B + 1) * Lpad * sizeof(float), 256);  // + the window envelope of the fold, [Lpad]
   if (plan->fam_ok) o += align_up(nf * plan->fam.fsf * sizeof(float), 256);
+  o += range_table_bytes(B);  // as in gl_layout
   total = o;
 }
 
@@ -1019,7 +1024,7 @@ static int read_call_options(const rfx_call_options* o, CallOpt* out, const char
 // InverseMelScale wrote it that way - so the once-per-call re-ordering of the plain frames is left out
 static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* d_angles0, uint64_t seed, int B, int T, int n_iter,
                           float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream,
-                          float* h_launch_ms, const CallOpt& opt, bool mag_in_fam_slots = false) {
+                          float* h_launch_ms, const CallOpt& opt, bool mag_in_fam_slots = false, const float* d_row_scale = nullptr) {
   const GenGeom& g = plan->gg;
   const int L = gen_out_len(g, T);
   if (n_iter > 0 && L <= g.n_fft / 2)
@@ -1034,6 +1039,12 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   float* gen[3];
   for (int i = 0; i < 3; ++i) gen[i] = (float*)(ws + oa) + (size_t)i * B * Lpad;  // x_k lives in gen[k % 3]
   float* env = (float*)(ws + oa) + (size_t)3 * B * Lpad;
+  if (!d_row_scale) {  // numeric range: from the caller's hint, else from the magnitudes themselves (one pass over them)
+    float* tab = (float*)(ws + total - range_table_bytes(B));
+    const size_t per_row = (size_t)T * ((plan->fam_ok && mag_in_fam_slots) ? (size_t)plan->fam.fsf : (size_t)g.fs);
+    RFX_HIP(launch_range_scale(d_mag, per_row, B, opt.magnitude_hint, (unsigned*)(tab + 2 * (size_t)B), nullptr, tab, 1, 0, stream));
+    d_row_scale = tab;
+  }
   RFX_HIP(launch_gen_env(plan->d_win, env, g, T, L, stream));
   // padded frame rows (gen_frame_layout): the kernels write the window samples only, the fold reads the padding as zeros
   if (g.fshift > 0) RFX_HIP(hipMemsetAsync(frames, 0, (size_t)B * T * g.fpitch * sizeof(float), stream));
@@ -1057,6 +1068,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     fa.fs_plain = g.fs;
     fa.audio_stride = (size_t)Lpad;
     fa.frames = frames;
+    fa.row_scale = d_row_scale;
     fa.fpitch = g.fpitch;
     fa.fshift = g.fshift;
     fa.tw1 = plan->d_fam_tw;
@@ -1078,7 +1090,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
       RFX_HIP(launch_fam_gl(it == 0 ? 0 : 1, fa, nblocks, stream));
       const bool last = it == n_iter;
       RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 2], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream,
-                              it == 0 ? nullptr : gen[(it + 1) % 2], last ? nullptr : gen[2], fa.mom));
+                              it == 0 ? nullptr : gen[(it + 1) % 2], last ? nullptr : gen[2], fa.mom, d_row_scale));
       if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
     }
     if (h_launch_ms) {
@@ -1094,6 +1106,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
   a.angles0 = (const cf*)d_angles0;
   a.audio_stride = (size_t)Lpad;
   a.frames = frames;
+  a.row_scale = d_row_scale;
   a.mom = momentum / (1.f + momentum);
   a.seed = seed;
   a.frame_base = opt.row_base * (uint64_t)T;
@@ -1110,7 +1123,7 @@ static int gen_griffinlim(const rfx_plan* plan, const float* d_mag, const void* 
     RFX_HIP(launch_gen_gl(it == 0 ? 0 : 1, a, plan->num_cus, stream));
     const bool last = it == n_iter;
     RFX_HIP(launch_gen_fold(frames, env, last ? d_wave_out : gen[it % 2], g, B, T, L, last ? (size_t)L : (size_t)Lpad, stream,
-                            it == 0 ? nullptr : gen[(it + 1) % 2], last ? nullptr : gen[2], a.mom));
+                            it == 0 ? nullptr : gen[(it + 1) % 2], last ? nullptr : gen[2], a.mom, d_row_scale));
     if (h_launch_ms) RFX_HIP(hipEventRecord(events.ev[it + 1], stream));
   }
   if (h_launch_ms) {
@@ -1136,7 +1149,7 @@ size_t rfx_griffinlim_workspace_bytes(const rfx_plan* plan, int B, int T) {
 
 static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const void* d_angles0_slots, uint64_t seed, int B,
                            int T, int n_iter, float momentum, float* d_wave_out, void* d_workspace, size_t workspace_bytes,
-                           void* stream_, float* h_launch_ms, const CallOpt& opt) {
+                           void* stream_, float* h_launch_ms, const CallOpt& opt, const float* d_row_scale = nullptr) {
   if (!plan || !d_mag_slots || !d_wave_out || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_griffinlim: null argument");
   if (B <= 0 || T < 2 || n_iter < 0) return fail(RFX_ERR_INVALID, "rfx_griffinlim: bad shape");
   if ((long long)B * T > 0x7fffffffLL) return fail(RFX_ERR_INVALID, "rfx_griffinlim: more than 2^31 - 1 frames in one call");
@@ -1144,7 +1157,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   if (plan->generic) {
     RFX_ON_DEVICE(plan->device);
     return gen_griffinlim(plan, d_mag_slots, d_angles0_slots, seed, B, T, n_iter, momentum, d_wave_out, d_workspace, workspace_bytes,
-                          (hipStream_t)stream_, h_launch_ms, opt);
+                          (hipStream_t)stream_, h_launch_ms, opt, false, d_row_scale);
   }
   // every iteration re-analyses the hop*(T-1)-sample estimate with torch.stft(center=True, reflect):
   // the reference raises there unless the signal is longer than the n_fft/2 padding
@@ -1167,6 +1180,11 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
 
   hipLaunchKernelGGL(out_scale_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, plan->d_win, scale, T, L);
   RFX_HIP(hipGetLastError());
+  if (!d_row_scale) {  // numeric range: from the caller's hint, else from the magnitudes themselves (one pass over them)
+    float* tab = (float*)(ws + total - range_table_bytes(B));
+    RFX_HIP(launch_range_scale(d_mag_slots, (size_t)T * kFrameStride, B, opt.magnitude_hint, (unsigned*)(tab + 2 * (size_t)B), nullptr, tab, 1, 0, stream));
+    d_row_scale = tab;
+  }
 
   if (gl_use_latency_mode(plan, B, T)) {
     // x_k lives in generation k % 3 (one folded buffer each: gen[k][0]); frame kernel + fold per iteration
@@ -1174,6 +1192,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
     fa.S = d_mag_slots;
     fa.angles0 = (const cf*)d_angles0_slots;
     fa.frames = (float*)(ws + off_frames);
+    fa.row_scale = d_row_scale;
     fa.tw1 = plan->d_tw1;
     fa.tw2 = plan->d_tw2;
     fa.win = plan->d_win;
@@ -1211,6 +1230,7 @@ static int griffinlim_impl(const rfx_plan* plan, const float* d_mag_slots, const
   g.S = d_mag_slots;
   g.angles0 = (const cf*)d_angles0_slots;
   g.out_scale = scale;
+  g.row_scale = d_row_scale;
   g.tw1 = plan->d_tw1;
   g.tw2 = plan->d_tw2;
   g.win = plan->d_win;
@@ -1512,7 +1532,7 @@ int rfx_mel_scale(const rfx_plan* plan, const float* d_lin_bft, int B, int T, fl
 
 size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T) {
   if (!plan || B <= 0 || T <= 0) return 0;
-  return align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256) + align_up((size_t)(B + 1) * sizeof(int), 256);
+  return align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256) + align_up((size_t)(B + 1) * sizeof(int), 256) + range_table_bytes(B);
 }
 
 // can InverseMelScale write a row-family plan's frames straight in the family kernels' slot order?  (Every kernel that leaves
@@ -1523,7 +1543,7 @@ static bool imel_can_emit_fam_slots(const rfx_plan* plan) {
 
 static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                             uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots,
-                            const CallOpt& opt);
+                            const CallOpt& opt, float* d_gl_row_scale = nullptr);
 
 int rfx_inverse_mel(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                     uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_) {
@@ -1540,7 +1560,7 @@ int rfx_inverse_mel_ex(const rfx_plan* plan, const float* d_mel, int B, int T, i
 
 static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,
                             uint64_t seed, float* d_mag_slots, void* d_workspace, size_t workspace_bytes, void* stream_, bool fam_slots,
-                            const CallOpt& opt) {
+                            const CallOpt& opt, float* d_gl_row_scale) {
   if (!plan || !d_mel || !d_mag_slots || !d_workspace) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: null argument");
   if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: plan was created without a mel filterbank");
   if (!plan->imel_ok) return fail(RFX_ERR_UNSUPPORTED, "rfx_inverse_mel: filterbank is not banded: " + plan->imel_why);
@@ -1557,7 +1577,15 @@ static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int
   int* it_stop = (int*)(ws + align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256));
   int* any_early = it_stop + nclips;
   RFX_HIP(hipMemsetAsync(any_early, 0, sizeof(int), stream));
+  // numeric range: the power of two each clip's SGD state is held in (and, for the fused call, the Griffin-Lim rows' factors),
+  // from the caller's hint or the clip's largest mel amplitude
+  float* clip_scale = (float*)(ws + align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256) + align_up((size_t)(B + 1) * sizeof(int), 256));
+  if (nclips > 65535) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: more than 65535 clips in one call");
+  RFX_HIP(launch_range_scale(d_mel, (size_t)channels_per_clip * plan->p.n_mels * T, nclips, opt.magnitude_hint, (unsigned*)(clip_scale + 2 * (size_t)nclips),
+                             clip_scale, d_gl_row_scale, channels_per_clip, 1, stream));
   ImelArgs a;
+  a.clip_scale = clip_scale;
+  a.sc = a.un = 0.f;
   a.tb = plan->imel;
   a.mel = d_mel;
   a.spec0 = d_spec0;
@@ -1599,7 +1627,7 @@ size_t rfx_waveform_from_mel_workspace_bytes(const rfx_plan* plan, int B, int T)
   const size_t imel = rfx_inverse_mel_workspace_bytes(plan, B, T), gl = rfx_griffinlim_workspace_bytes(plan, B, T);
   if (!imel || !gl) return 0;
   const size_t stride = imel_can_emit_fam_slots(plan) ? (size_t)plan->fam.fsf : (size_t)plan->frame_stride;
-  return align_up((size_t)B * T * stride * sizeof(float), 256) + (imel > gl ? imel : gl);
+  return align_up((size_t)B * T * stride * sizeof(float), 256) + range_table_bytes(B) + (imel > gl ? imel : gl);
 }
 
 static int waveform_from_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, uint64_t seed, int n_iter,
@@ -1629,12 +1657,14 @@ static int waveform_from_mel_impl(const rfx_plan* plan, const float* d_mel, int 
   // re-ordering of plain frames (0.75 ms and 2.5 GB of traffic per 64 tiles at 48 kHz) exists only for callers of the two entry points
   const bool fam_slots = imel_can_emit_fam_slots(plan);
   const size_t lin_bytes = align_up((size_t)B * T * (fam_slots ? (size_t)plan->fam.fsf : (size_t)plan->frame_stride) * sizeof(float), 256);
-  void* rest = (char*)d_workspace + lin_bytes;
-  if (int rc = inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, nullptr, seed, lin, rest, workspace_bytes - lin_bytes, stream, fam_slots, opt)) return rc;
-  if (!fam_slots) return griffinlim_impl(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, stream, nullptr, opt);
+  float* row_scale = reinterpret_cast<float*>((char*)d_workspace + lin_bytes);  // written by the SGD stage's range pass, read by Griffin-Lim
+  const size_t head = lin_bytes + range_table_bytes(B);
+  void* rest = (char*)d_workspace + head;
+  if (int rc = inverse_mel_impl(plan, d_mel, B, T, channels_per_clip, nullptr, seed, lin, rest, workspace_bytes - head, stream, fam_slots, opt, row_scale)) return rc;
+  if (!fam_slots) return griffinlim_impl(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - head, stream, nullptr, opt, row_scale);
   if (T < 2 || n_iter < 0 || (long long)B * T > 0x7fffffffLL || !(momentum >= 0.f && momentum < 1.f)) return fail(RFX_ERR_INVALID, "rfx_waveform_from_mel: bad shape");
   RFX_ON_DEVICE(plan->device);
-  return gen_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - lin_bytes, (hipStream_t)stream, nullptr, opt, true);
+  return gen_griffinlim(plan, lin, nullptr, seed + 1, B, T, n_iter, momentum, d_wave_out, rest, workspace_bytes - head, (hipStream_t)stream, nullptr, opt, true, row_scale);
 }
 
 int rfx_image_decode_u8(const uint8_t* d_img, int N, int H, int W, int stereo, const float* d_lut256, float* d_mel_out,

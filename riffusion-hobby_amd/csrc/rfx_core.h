@@ -534,7 +534,11 @@ RFX_HD void p3_inverse(cf* cube, cf (&Z)[21], TW tw2, int k1, int ka, STAGE stag
 // `a` below is already rebuilt - m*tprev: the STFT is linear, so the kernels analyse the signal
 // x_k - m*x_{k-1} instead of subtracting two spectra (see rfx_gl.hip).
 // ------------------------------------------------------------------------------------------------
-RFX_HD cf gl_project(cf a, float S) {
+// Round 6: `eps2` is the square of that 1e-16 in the units `a` arrives in.  The kernels analyse the signal times a power of two
+// per row (GlRowScale: the row's magnitudes brought to the 2^25 the path was tuned and tested at), so that re^2 + im^2 can
+// neither overflow (|a| > 1.8e19 squared to inf, rsq gave 0: silence, at max_value 1e20) nor vanish; the factor S / (|a| + eps)
+// is the unscaled one up to that power of two, which the product with the scaled `a` cancels: the result is S * angles as before.
+RFX_HD cf gl_project(cf a, float S, float eps2 = 1e-32f) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef RFX_PROJECT_SQRT_RCP
   // One quarter-rate instruction per bin: S / (|a| + 1e-16) = S * rsq(|a|^2 + 1e-32) up to fp32 rounding
@@ -542,7 +546,7 @@ RFX_HD cf gl_project(cf a, float S) {
   // reference.  Only for 0 < |a| < 1e-8 - thirteen orders of magnitude below the spectra this path sees -
   // does the factor differ (it stays bounded by 1e16 either way); tests/test_gpu_stft_gl.py covers the
   // zero and tiny-magnitude cases.  v_rsq_f32 is 1 ulp, like the v_sqrt_f32 / v_rcp_f32 pair it replaces.
-  const float sc = S * __builtin_amdgcn_rsqf(fmaf(a.re, a.re, fmaf(a.im, a.im, 1e-32f)));
+  const float sc = S * __builtin_amdgcn_rsqf(fmaf(a.re, a.re, fmaf(a.im, a.im, eps2)));
 #else
   // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sqrt / divide expansions
   const float mag = __builtin_amdgcn_sqrtf(fmaf(a.re, a.re, a.im * a.im));

@@ -236,8 +236,9 @@ __global__ void __launch_bounds__(fam_threads(RA, RB, NR)) __attribute__((amdgpu
       __builtin_amdgcn_s_setprio(2);
 #endif
       fam_pass_b_forward<RA, RB, VEC>(rowb, 0, R);
+      const float eps2 = a.row_scale ? a.row_scale[2 * (gf / a.T) + 1] : 1e-32f;  // (the fold has applied row_scale[2 row] to x_cur)
 #pragma unroll
-      for (int s = 0; s < RB; ++s) R[s] = gl_project(R[s], Sv[s]);
+      for (int s = 0; s < RB; ++s) R[s] = gl_project(R[s], Sv[s], eps2);
     } else {
       const unsigned rng_key = rand_frame_key(a.seed, a.frame_base + (unsigned long long)gf);  // the generic engine's stream
 #pragma unroll

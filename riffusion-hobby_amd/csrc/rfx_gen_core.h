@@ -592,17 +592,17 @@ RFX_HD void gen_pair_load(GenPair& p, const GenGeom& g, const cf* Z, AT at, cons
 // and back, with S = X'[k] + conj X'[nc-k], D = X'[k] - conj X'[nc-k], P = D conj(w):
 //     Z'[k] = (S + i P) / 2,  Z'[nc-k] = conj((S - i P) / 2)
 // (two complex multiplications and one twiddle per pair; the four gen_split_*_vals calls they replace fetched four).
-RFX_HD void gen_pair_compute(GenPair& p, const GenGeom& g, const cf* lo2, const cf* hi2) {
+RFX_HD void gen_pair_compute(GenPair& p, const GenGeom& g, const cf* lo2, const cf* hi2, float eps2 = 1e-32f) {
   const int k = p.k;
   if (!g.even) {
-    const cf X = gl_project(p.zk, p.sk);
+    const cf X = gl_project(p.zk, p.sk, eps2);
     p.zk = k == 0 ? cf{X.re, 0.f} : X;  // the c2r transform ignores the imaginary part of bin 0
     p.zc = cf{X.re, -X.im};
     return;
   }
   if (k == 0) {
-    const cf X0 = gl_project(gen_split_forward_vals(g, p.zk, p.zk, lo2, hi2, 0), p.sk);
-    const cf Xn = gl_project(gen_split_forward_vals(g, p.zk, p.zk, lo2, hi2, g.nc), p.sc);
+    const cf X0 = gl_project(gen_split_forward_vals(g, p.zk, p.zk, lo2, hi2, 0), p.sk, eps2);
+    const cf Xn = gl_project(gen_split_forward_vals(g, p.zk, p.zk, lo2, hi2, g.nc), p.sc, eps2);
     p.zk = gen_split_inverse_vals(g, X0, Xn, lo2, hi2, 0);
     return;
   }
@@ -610,8 +610,8 @@ RFX_HD void gen_pair_compute(GenPair& p, const GenGeom& g, const cf* lo2, const 
   const cf s{p.zk.re + p.zc.re, p.zk.im - p.zc.im}, d{p.zk.re - p.zc.re, p.zk.im + p.zc.im};
   const cf q = cmul(w, d);
   // X[k] = (s - i q) / 2 ; X[nc-k] = conj((s + i q) / 2)
-  const cf Xk = gl_project(cf{0.5f * (s.re + q.im), 0.5f * (s.im - q.re)}, p.sk);
-  const cf Xc = gl_project(cf{0.5f * (s.re - q.im), -0.5f * (s.im + q.re)}, p.sc);
+  const cf Xk = gl_project(cf{0.5f * (s.re + q.im), 0.5f * (s.im - q.re)}, p.sk, eps2);
+  const cf Xc = gl_project(cf{0.5f * (s.re - q.im), -0.5f * (s.im + q.re)}, p.sc, eps2);
   const cf S{Xk.re + Xc.re, Xk.im - Xc.im}, D{Xk.re - Xc.re, Xk.im + Xc.im};
   const cf P = cmulc(D, w);
   // Z'[k] = (S + i P) / 2 ; Z'[nc-k] = conj((S - i P) / 2)
@@ -628,10 +628,10 @@ RFX_HD void gen_pair_store(const GenPair& p, const GenGeom& g, cf* Z, AT at) {
   }
 }
 template <class AT>
-RFX_HD void gen_pair_project(const GenGeom& g, cf* Z, AT at, const float* S, const cf* lo2, const cf* hi2, int k) {
+RFX_HD void gen_pair_project(const GenGeom& g, cf* Z, AT at, const float* S, const cf* lo2, const cf* hi2, int k, float eps2 = 1e-32f) {
   GenPair p;
   gen_pair_load(p, g, Z, at, S, k);
-  gen_pair_compute(p, g, lo2, hi2);
+  gen_pair_compute(p, g, lo2, hi2, eps2);
   gen_pair_store(p, g, Z, at);
 }
 // number of gen_pair_project calls per frame

@@ -164,6 +164,8 @@ gen_gl_kernel(GenGlArgs a) {
 #endif
   for (long long fr = blockIdx.x; fr < nframes; fr += gridDim.x) {
     const int clip = (int)(fr / a.T), t = (int)(fr - (long long)clip * a.T);
+    const float eps2 = a.row_scale ? a.row_scale[2 * clip + 1] : 1e-32f;
+    (void)eps2;
     const size_t base = (size_t)fr * g.fs;
     const float* __restrict__ S = a.S + base;
     __syncthreads();  // the previous frame's output loop is done with the buffer
@@ -247,7 +249,7 @@ gen_gl_kernel(GenGlArgs a) {
             pr[u].zc = g.even ? l.a[pc[u]] : pr[u].zk;
           }
 #pragma unroll
-          for (int u = 0; u < UP; ++u) gen_pair_compute(pr[u], g, l.lo2, l.hi2);
+          for (int u = 0; u < UP; ++u) gen_pair_compute(pr[u], g, l.lo2, l.hi2, eps2);
 #pragma unroll
           for (int u = 0; u < UP; ++u) {
             const int k = k0 + u * nthr;
@@ -330,7 +332,8 @@ __global__ void __launch_bounds__(256) gen_env_kernel(const float* __restrict__ 
 // anyway.  Same fma as the kernel used to do: same bits.
 __global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__ frames, const float* __restrict__ env,
                                                        float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride,
-                                                       const float* __restrict__ prev, float* __restrict__ dout, float mom) {
+                                                       const float* __restrict__ prev, float* __restrict__ dout, float mom,
+                                                       const float* __restrict__ row_scale) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (p >= L) return;
@@ -341,11 +344,13 @@ __global__ void __launch_bounds__(256) gen_fold_kernel(const float* __restrict__
   for (int t = tlo; t <= thi; ++t) acc += frames[((size_t)b * T + t) * g.fpitch + g.fshift + (q - g.hop * t)];
   const float x = acc / env[p];
   out[(size_t)b * out_stride + p] = x;
-  if (dout) dout[(size_t)b * out_stride + p] = prev ? fmaf(-mom, prev[(size_t)b * out_stride + p], x) : x;
+  const float ks = row_scale ? row_scale[2 * b] : 1.f;  // a power of two (GlArgs::row_scale)
+  if (dout) dout[(size_t)b * out_stride + p] = ks * (prev ? fmaf(-mom, prev[(size_t)b * out_stride + p], x) : x);
 }
 __global__ void __launch_bounds__(256) gen_fold4_kernel(const float* __restrict__ frames, const float* __restrict__ env,
                                                         float* __restrict__ out, GenGeom g, int B, int T, int L, size_t out_stride,
-                                                        const float* __restrict__ prev, float* __restrict__ dout, float mom) {
+                                                        const float* __restrict__ prev, float* __restrict__ dout, float mom,
+                                                        const float* __restrict__ row_scale) {
   using v4 = float __attribute__((ext_vector_type(4)));
   const int p = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
   const int b = blockIdx.y;
@@ -369,7 +374,8 @@ __global__ void __launch_bounds__(256) gen_fold4_kernel(const float* __restrict_
       const v4 xp = *reinterpret_cast<const v4*>(prev + (size_t)b * out_stride + p);
       d = v4{fmaf(-mom, xp.x, x.x), fmaf(-mom, xp.y, x.y), fmaf(-mom, xp.z, x.z), fmaf(-mom, xp.w, x.w)};
     }
-    *reinterpret_cast<v4*>(dout + (size_t)b * out_stride + p) = d;
+    const float ks = row_scale ? row_scale[2 * b] : 1.f;
+    *reinterpret_cast<v4*>(dout + (size_t)b * out_stride + p) = v4{ks * d.x, ks * d.y, ks * d.z, ks * d.w};
   }
 }
 
@@ -498,12 +504,12 @@ hipError_t launch_gen_env(const float* win, float* env, const GenGeom& g, int T,
   return hipGetLastError();
 }
 hipError_t launch_gen_fold(const float* frames, const float* env, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
-                           hipStream_t stream, const float* prev, float* dout, float mom) {
+                           hipStream_t stream, const float* prev, float* dout, float mom, const float* row_scale) {
   const bool vec = g.fpitch % 4 == 0 && g.hop % 4 == 0 && (g.n_fft / 2 - g.left + g.fshift) % 4 == 0 && L % 4 == 0 && out_stride % 4 == 0 &&
                    (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(env) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(prev) & 15) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(gen_fold4_kernel, dim3((L / 4 + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride, prev, dout, mom);
-  else hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride, prev, dout, mom);
+  if (vec) hipLaunchKernelGGL(gen_fold4_kernel, dim3((L / 4 + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride, prev, dout, mom, row_scale);
+  else hipLaunchKernelGGL(gen_fold_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, frames, env, out, g, B, T, L, out_stride, prev, dout, mom, row_scale);
   return hipGetLastError();
 }
 

@@ -119,6 +119,10 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   const rsrc_t in1 = make_rsrc(g.audio_in[1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t pv0 = make_rsrc(g.audio_prev[0] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
   const rsrc_t pv1 = make_rsrc(g.audio_prev[1] + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+  // numeric range (round 6): the row's analysis input times a power of two, eps^2 in those units (GlArgs::row_scale)
+  const float ks = g.row_scale ? g.row_scale[2 * clip] : 1.f, eps2 = g.row_scale ? g.row_scale[2 * clip + 1] : 1e-32f;
+  (void)ks;
+  (void)eps2;
   // the group of the frame being synthesised: [tg0, tg1], its partial sums go to the buffer of its parity (outA), explicit zeros
   // for blocks no other group touches to the other one (outB); t0 is a group start (runs are whole groups)
   int tg0 = t0, tg1 = min(g.T - 1, t0 + kGlGroup - 1);
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   auto combine_d = [&](const DRaw& r) {
     float x = r.a0 + r.a1;
     if (MODE == 2) x = fmaf(-g.mom, r.p0 + r.p1, x);
-    return x;
+    return x * ks;
   };
   auto load_d = [&](int blk) { return combine_d(request_d(blk)); };
   float d[10];
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
 #endif
       // ---- angles = a / (|a| + 1e-16);  next spectrum estimate Z = |S| * angles
 #pragma unroll
-      for (int kb = 0; kb < 21; ++kb) R[kb] = gl_project(R[kb], mag_at(mag, kb));
+      for (int kb = 0; kb < 21; ++kb) R[kb] = gl_project(R[kb], mag_at(mag, kb), eps2);
     } else {
       // ---- Z = |S| * angles0 with angles0 injected or drawn (rand_init=True, spectrogram_converter.py:72:
       // U[0,1) real and imaginary parts per BIN; a conjugate slot conjugates its primary's draw)
@@ -377,17 +381,18 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_frame_kernel(GlFra
     if (MODE != 0) {
       const rsrc_t in = make_rsrc(g.audio_in + (size_t)clip * g.Lpad, (size_t)g.L * 4);
       const rsrc_t pv = make_rsrc(g.audio_prev + (size_t)clip * g.Lpad, (size_t)g.L * 4);
+      const float ks = g.row_scale ? g.row_scale[2 * clip] : 1.f, eps2 = g.row_scale ? g.row_scale[2 * clip + 1] : 1e-32f;
       float u[10];
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
         const unsigned p4 = (unsigned)reflect_index((fr + j - kHalfHops) * kHop + t.npr, g.L) * 4u;
         float x = ld1(in, p4, 0);
         if (MODE == 2) x = fmaf(-g.mom, ld1(pv, p4, 0), x);
-        u[j] = x * wv[j];
+        u[j] = (x * ks) * wv[j];  // (the run kernel scales when the sample enters its sliding window: same two products)
       }
       frame_forward_tw(u, R, f, t, tw1, [&] { mag_issue(mag, Ssrc, foff, q16); });
 #pragma unroll
-      for (int kb = 0; kb < 21; ++kb) R[kb] = gl_project(R[kb], mag_at(mag, kb));
+      for (int kb = 0; kb < 21; ++kb) R[kb] = gl_project(R[kb], mag_at(mag, kb), eps2);
     } else {
       mag_issue(mag, Ssrc, foff, q16);
       if (g.angles0) {

@@ -249,8 +249,18 @@ __device__ __forceinline__ void imel_emit_frame(const ImelArgs& a, const float* 
 //    spec values drift inside [0, 1] and touch nothing).  Unlike the power-of-two scaling above this is NOT bit-identical to
 //    the two-weight form: the weights sum to one only to 1e-6 and the gradient is rounded differently; emulated on the CPU
 //    against the oracle the two forms sit at the same distance (rel-L2 2.1e-7 both).
-constexpr float kImelScale = 8.673617379884035e-19f;    // 2^-60
+// Round 6: the exponent is per CLIP, chosen from the clip's largest mel amplitude (or the caller's magnitude_hint) by
+// imel_range_kernel below so that the largest target sits near 2^-35 whatever the units are - 2^-60 for the reference's default
+// max_value = 30e6, as in rounds 2-5, and the same bits for ANY power of two (the scale commutes with rounding).  A fixed 2^-60
+// saturated silently above 1.15e18 and flushed below 1.4e-20 in the reference's units; now the supported range is the one
+// include/rfx.h states ("Numeric range").
+constexpr float kImelScale = 8.673617379884035e-19f;    // 2^-60: without a per-clip table (ImelArgs::clip_scale == nullptr)
 constexpr float kImelUnscale = 1152921504606846976.0f;  // 2^60
+// sets a.sc / a.un (scale into the state's units / back) for the frame's clip
+__device__ __forceinline__ void imel_set_scale(ImelArgs& a, int clip) {
+  a.sc = a.clip_scale ? a.clip_scale[2 * clip] : kImelScale;
+  a.un = a.clip_scale ? a.clip_scale[2 * clip + 1] : kImelUnscale;
+}
 #ifndef RFX_IMEL_CLAMP
 #define RFX_IMEL_CLAMP 1
 #endif
@@ -422,7 +432,7 @@ __device__ __forceinline__ void group_stage(const GroupState<N, UF>& g, const Im
 // this wave's workgroup slot works on, `live` false for a slot past the last frame (it runs the same barriers on a copy of
 // the last frame's data and stores nothing).
 template <int NLO, int NHI, bool UF>
-__device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, int tid, int frame, bool live) {
+__device__ __forceinline__ void imel_group_body(ImelArgs a, char* smem, int tid, int frame, bool live) {
   const ImelTables& tb = a.tb;
   const int M = a.M;
   float* Ab = reinterpret_cast<float*>(smem);  // [2][M + 4], entry m at index m + 1
@@ -434,12 +444,13 @@ __device__ __forceinline__ void imel_group_body(const ImelArgs& a, char* smem, i
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass (one frame per workgroup): this clip never stopped early
   const unsigned rbase = rand_frame_key(a.seed, a.frame_base + (unsigned long long)frame);
+  imel_set_scale(a, clip);
 
   const int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;           // long groups, counted down from the top
   const int gL = (tid < M - kImelThreads) ? tid : -1;             // short groups, counted up from 0
   // the short groups keep both weights (the lowest bins sit below the first filter's centre and feed one filter only);
   // the long groups run in unit form when the plan found the bank fit for it (UF)
-  constexpr float kScale = RFX_IMEL_CLAMP ? kImelScale : 1.f, kUnscale = RFX_IMEL_CLAMP ? kImelUnscale : 1.f;
+  const float kScale = RFX_IMEL_CLAMP ? a.sc : 1.f, kUnscale = RFX_IMEL_CLAMP ? a.un : 1.f;
   GroupState<NLO, false> lo;
   GroupState<NHI, UF> hi;
   group_load(lo, gL, a, frame, rbase, kScale);
@@ -632,14 +643,14 @@ __device__ __forceinline__ void wv_load(WvChunk<NP, NF, UF>& k, int g, const Ime
   k.s0 = tb.lin[a.M + g];
   k.a1 = tb.lin[2 * a.M + g];
   k.s1 = tb.lin[3 * a.M + g];
-  k.m0 = kImelScale * a.mel[((size_t)b * a.M + g) * a.T + t];
+  k.m0 = a.sc * a.mel[((size_t)b * a.M + g) * a.T + t];
   k.C = 0.f;
   k.G = 0.f;
 #pragma unroll
   for (int i = 0; i < 2 * NP; ++i) {
     const bool ok = i < n;
     const int f = f0 + (ok ? i : 0);
-    const float sp = ok ? kImelScale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
+    const float sp = ok ? a.sc * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
     if (i & 1) k.spec[i >> 1].y = sp; else k.spec[i >> 1].x = sp;
     if (i >= 2 * NF) {
       if (i & 1) k.mask[(i >> 1) - NF].y = ok ? 1.f : 0.f; else k.mask[(i >> 1) - NF].x = ok ? 1.f : 0.f;
@@ -677,11 +688,11 @@ __device__ __forceinline__ void wv_update(WvChunk<NP, NF, UF>& k, float vx, floa
 }
 // the chunk's bins, unscaled, into the frame's LDS stage (bin order: entry f - f_lo)
 template <int NP, int NF, bool UF>
-__device__ __forceinline__ void wv_stage(const WvChunk<NP, NF, UF>& k, int g, const ImelTables& tb, float* stage) {
+__device__ __forceinline__ void wv_stage(const WvChunk<NP, NF, UF>& k, int g, const ImelTables& tb, float* stage, float unscale) {
   const int f0 = tb.grp_start[g], n = tb.grp_start[g + 1] - f0;
 #pragma unroll
   for (int i = 0; i < 2 * NP; ++i)
-    if (i < n) stage[f0 + i - tb.f_lo] = kImelUnscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
+    if (i < n) stage[f0 + i - tb.f_lo] = unscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -716,7 +727,7 @@ __device__ __forceinline__ void line_load(LineGroup<NP, UF>& k, int g, const Ime
   for (int i = 0; i < 2 * NP; ++i) {
     const bool ok = i < n;
     const int f = f0 + (ok ? i : 0);
-    const float sp = ok ? kImelScale * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
+    const float sp = ok ? a.sc * (a.spec0 ? a.spec0[(size_t)frame * a.n_stft + f] : rand_unit(rbase, f)) : 0.f;
     if (i & 1) { k.spec[i >> 1].y = sp; k.mask[i >> 1].y = ok ? 1.f : 0.f; }
     else       { k.spec[i >> 1].x = sp; k.mask[i >> 1].x = ok ? 1.f : 0.f; }
   }
@@ -760,17 +771,17 @@ __device__ __forceinline__ void line_step(LineGroup<NP, UF>& k, float n0, float 
   }
 }
 template <int NP, bool UF>
-__device__ __forceinline__ void line_stage(const LineGroup<NP, UF>& k, int g, const ImelTables& tb, float* stage) {
+__device__ __forceinline__ void line_stage(const LineGroup<NP, UF>& k, int g, const ImelTables& tb, float* stage, float unscale) {
   if (g < 0) return;
   const int f0 = tb.grp_start[g], n = tb.grp_start[g + 1] - f0;
 #pragma unroll
   for (int i = 0; i < 2 * NP; ++i)
-    if (i < n) stage[f0 + i - tb.f_lo] = kImelUnscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
+    if (i < n) stage[f0 + i - tb.f_lo] = unscale * ((i & 1) ? k.spec[i >> 1].y : k.spec[i >> 1].x);
 }
 
 // the group body (imel_group_body) with the long group in line form; same roles, same LDS layout, same barriers
 template <int NLO, int NHI, bool UF>
-__device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, int tid, int frame) {
+__device__ __forceinline__ void imel_line_body(ImelArgs a, char* smem, int tid, int frame) {
   const ImelTables& tb = a.tb;
   const int M = a.M;
   float* Ab = reinterpret_cast<float*>(smem);  // [2][M + 4], entry m at index m + 1
@@ -781,6 +792,7 @@ __device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, in
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
   const unsigned rbase = rand_frame_key(a.seed, a.frame_base + (unsigned long long)frame);
+  imel_set_scale(a, clip);
   int gH = (M - 1 - tid >= 0) ? M - 1 - tid : -1;
   int gL = (tid < M - kImelThreads) ? tid : -1;
   if (gH >= 0 && gH < tb.line_from) {  // a long group that is not a line: into the (free: the plan checked) table-form slot
@@ -789,9 +801,9 @@ __device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, in
   }
   GroupState<NLO, false> lo;
   LineGroup<(NHI + 1) / 2, UF> hi;
-  group_load(lo, gL, a, frame, rbase, kImelScale);
+  group_load(lo, gL, a, frame, rbase, a.sc);
   line_load(hi, gH, a, frame, rbase);
-  auto melat = [&](int m) { return (m >= 0 && m < M) ? kImelScale * a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
+  auto melat = [&](int m) { return (m >= 0 && m < M) ? a.sc * a.mel[((size_t)b * M + m) * a.T + t] : 0.f; };
   const float mL0 = gL >= 0 ? melat(gL) : 0.f, mL1 = gL >= 0 ? melat(gL + 1) : 0.f;
   const float mH0 = gH >= 0 ? melat(gH) : 0.f, mH1 = gH >= 0 ? melat(gH + 1) : 0.f;
   for (int i = tid; i < 4 * (M + 4); i += kImelThreads) Ab[i] = 0.f;
@@ -816,7 +828,7 @@ __device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, in
     const float dL1 = mL1 - aLp - BL;
     const float dH0 = mH0 - AH - bHm;
     const float dH1 = noH1 ? 0.f : mH1 - aHp - BH;
-    const float uL = kImelUnscale * dL0, uH = kImelUnscale * dH0;
+    const float uL = a.un * dL0, uH = a.un * dH0;
     const float sq = wave_sum(fmaf(uL, uL, uH * uH));
     if ((tid & 63) == 0) part[4 * it + wave] = sq;
     group_step(lo, dL0, dL1, a.momentum, nl2);
@@ -832,8 +844,8 @@ __device__ __forceinline__ void imel_line_body(const ImelArgs& a, char* smem, in
   __syncthreads();
 
   float* stage = reinterpret_cast<float*>(smem + imel_group_lds_bytes(M, a.max_iter));
-  group_stage(lo, tb, stage, kImelUnscale);
-  line_stage(hi, gH, tb, stage);
+  group_stage(lo, tb, stage, a.un);
+  line_stage(hi, gH, tb, stage, a.un);
   __syncthreads();
   imel_emit_frame(a, stage, frame, rbase, tid, kImelThreads);
   if (a.loss_hist && !a.it_limit)
@@ -870,6 +882,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int steps = a.it_limit ? a.it_limit[clip] : a.max_iter;
   if (a.it_limit && steps >= a.max_iter) return;  // fix-up pass: this clip never stopped early
   const unsigned rbase = rand_frame_key(a.seed, a.frame_base + (unsigned long long)frame);
+  imel_set_scale(a, clip);
   for (int i = lane; i < a.max_iter; i += 64) part[i] = 0.f;
   const unsigned part_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address of part[0]
 
@@ -924,7 +937,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #undef RFX_WV_R2
 #ifndef RFX_ABL_IMEL_NO_LOSS
     {  // every filter's residual is owned exactly once; the loss history is kept in the reference's units
-#define RFX_WV_L1(c) const float u##c = kImelUnscale * d0##c;
+#define RFX_WV_L1(c) const float u##c = a.un * d0##c;
       RFX_WV_CHUNKS(RFX_WV_L1)
 #undef RFX_WV_L1
       const float sqa = fmaf(u6, u6, fmaf(u4, u4, fmaf(u2, u2, u0 * u0))), sqb = fmaf(u7, u7, fmaf(u5, u5, fmaf(u3, u3, u1 * u1)));
@@ -967,7 +980,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // the frame leaves through the LDS stage (imel_emit_frame): active bins parked in bin order, then one walk over the positions
   float* stage = part + a.max_iter;  // [f_hi - f_lo]
-#define RFX_WV_STAGE(c) wv_stage(k##c, imel_wave_group(c, lane), tb, stage);
+#define RFX_WV_STAGE(c) wv_stage(k##c, imel_wave_group(c, lane), tb, stage, a.un);
   RFX_WV_CHUNKS(RFX_WV_STAGE)
 #undef RFX_WV_STAGE
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // one wave: its LDS operations execute in order, the compiler must keep them so
@@ -1088,6 +1101,64 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)imel_kernel<36>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(imel_kernel<36>, dim3(a.B * a.T), dim3(kImelThreads), lds, stream, a);
   }
+  return hipGetLastError();
+}
+
+// ---- numeric range (round 6): the powers of two the SGD and Griffin-Lim kernels work in, per clip / per row ----------------------
+// max |x| per group as an integer key (the bits of a non-negative float order like the float; NaN is skipped, as fmaxf does)
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+  return x;
+}
+__global__ void __launch_bounds__(256) range_max_kernel(const float* __restrict__ x, size_t count, unsigned* __restrict__ keys) {
+  const float* p = x + (size_t)blockIdx.y * count;
+  float mx = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(p[i]));
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&keys[blockIdx.y], __float_as_uint(mx));
+}
+__global__ void __launch_bounds__(64) range_finish_kernel(const unsigned* __restrict__ keys, int groups, float hint, float* __restrict__ imel_scale,
+                                                          float* __restrict__ gl_scale, int rows, int mel_units) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= groups) return;
+  const float mx = hint > 0.f ? hint : __uint_as_float(keys[g]);
+  int k = 0;  // mx in [2^(k-1), 2^k); an all-zero (or all-NaN) group works in the default units
+  if (mx > 0.f) {
+    if (mx < __builtin_inff()) (void)frexpf(mx, &k);
+    else k = 129;
+  }
+  if (imel_scale) {
+    // the clip's largest target near 2^-35 of the clamp's upper bound (2^-60 for max_value = 30e6, as in rounds 2-5); never above
+    // 2^-30: the untouched bins start at U[0, 1) in the reference's units whatever the targets are
+    int e = k + 35;
+    e = e < 30 ? 30 : (e > 126 ? 126 : e);
+    imel_scale[2 * g] = ldexpf(1.f, -e);
+    imel_scale[2 * g + 1] = ldexpf(1.f, e);
+  }
+  if (gl_scale) {
+    const int ks = mel_units ? (k > 0 ? k : 0) + 1 : k;
+    int j = ks - 26;  // the row's largest magnitude near 2^25: what 30e6 gives unscaled (j = 0)
+    j = j < -100 ? -100 : (j > 100 ? 100 : j);
+    const float eps2 = fmaxf(ldexpf(1e-32f, -2 * j), 1.17549435e-38f);  // never zero: 0 * rsq(0 + 0) would be NaN where the reference gives 0
+    for (int r = 0; r < rows; ++r) {
+      gl_scale[2 * ((size_t)g * rows + r)] = ldexpf(1.f, -j);
+      gl_scale[2 * ((size_t)g * rows + r) + 1] = eps2;
+    }
+  }
+}
+hipError_t launch_range_scale(const float* x, size_t count, int groups, float hint, unsigned* keys, float* imel_scale, float* gl_scale, int rows,
+                              int mel_units, hipStream_t stream) {
+  if (!(hint > 0.f)) {
+    hipError_t e = hipMemsetAsync(keys, 0, sizeof(unsigned) * (size_t)groups, stream);
+    if (e != hipSuccess) return e;
+    size_t chunks = (count + 256 * 64 - 1) / (256 * 64);  // ~64 values per thread
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(range_max_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), 0, stream, x, count, keys);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(range_finish_kernel, dim3((groups + 63) / 64), dim3(64), 0, stream, keys, groups, hint, imel_scale, gl_scale, rows, mel_units);
   return hipGetLastError();
 }
 

@@ -9,8 +9,12 @@
 
 namespace rfx {
 
+// Per-row numeric range of Griffin-Lim (round 6): row r of a call analyses its signal times row_scale[2 r] (a power of two that
+// brings the row's magnitudes to about 2^25) and projects with eps^2 = row_scale[2 r + 1] (rfx_core.h::gl_project); written by
+// range_scale_kernel (rfx_imel.hip) from the data or the caller's magnitude_hint.  A null table means {1, 1e-32}.
 struct GlArgs {
   const float* S;             // [B*T][kFrameStride] magnitudes, slot_pos_f order
+  const float* row_scale;     // [B][2] or null
   const cf* angles0;          // optional injected initial angles, slot_pos_c order (MODE 0)
   const float* audio_in[2];   // parity partial sums of x_k, the current estimate, [B][Lpad]
   const float* audio_prev[2]; // parity partial sums of x_{k-1} (MODE 2)
@@ -77,6 +81,7 @@ struct GlFrameArgs {
   const float* audio_in;    // x_k      [B][Lpad]
   const float* audio_prev;  // x_{k-1}  (MODE 2)
   float* frames;            // [B*T][4416] windowed synthesis frames
+  const float* row_scale;   // [B][2] or null (see GlArgs)
   const cf* tw1;
   const cf* tw2;
   const float* win;
@@ -218,6 +223,8 @@ struct ImelArgs {
   const float* mel;      // [B][M][T]
   const float* spec0;    // optional [B][T][n_stft] injected init (reference layout), else seeded RNG
   float* out_slots;      // [B*T][kFrameStride]
+  const float* clip_scale;  // [nclips][2] {2^-e, 2^e}: the power of two the clip's SGD state is held in (range_scale_kernel), null = 2^-60
+  float sc, un;             // the frame's pair, set inside the kernels (imel_set_scale)
   float* loss_hist;      // [B*T][max_iter] per-frame sum_m diff^2 before each step
   const int* it_limit;   // optional [nclips] number of steps to run (fix-up pass), NULL = max_iter
   int B, M, T, C;        // C = channels per clip (the loss mean couples them)
@@ -231,6 +238,14 @@ struct ImelArgs {
 };
 hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream);  // variant: 0 best, 1 uniform groups, 2 general
 // scans loss_hist for the early-stop condition; it_stop[clip] = steps the reference would have run
+// Numeric range (round 6, include/rfx.h): one workgroup per group of `count` contiguous floats of x (a clip's mel amplitudes, or a
+// row's magnitudes) takes max |x| - or `hint` when > 0, without reading x - and writes the powers of two the kernels work in:
+//   imel_scale[g] = {2^-e, 2^e}, e = max(k + 35, 30) for max in [2^(k-1), 2^k)     (nullable)
+//   gl_scale[g * rows + r] = {2^-j, eps^2}, j = ks - 26, ks = k, or max(k, 0) + 1 when `mel_units` (the SGD's untouched bins keep
+//   their U[0,1) start: a row's magnitudes reach 1 whatever the mel amplitudes are)                         (nullable)
+// keys: [groups] scratch words.  groups <= 65535 per launch (grid y).
+hipError_t launch_range_scale(const float* x, size_t count, int groups, float hint, unsigned* keys, float* imel_scale, float* gl_scale, int rows,
+                              int mel_units, hipStream_t stream);
 hipError_t launch_imel_scan(const float* loss_hist, int* it_stop, int* any_early, int nclips, int C, int T, int max_iter,
                             float tol_loss, float tol_change, hipStream_t stream);
 
@@ -264,6 +279,7 @@ struct GenGlArgs {
   const float* x_prev;   // unused since round 4 (the kernel used to form d itself from x_k and x_{k-1})
   size_t audio_stride;
   float* frames;         // [B*T][win] windowed, scaled synthesis frames (gen_fold_kernel overlap-adds them)
+  const float* row_scale;  // [B][2] or null (see GlArgs): the fold applies the factor to d, the kernel takes eps^2 from it
   float mom;             // momentum / (1 + momentum)
   unsigned long long seed;
   unsigned long long frame_base;  // as GlArgs::frame_base
@@ -275,7 +291,8 @@ hipError_t launch_gen_stft(int mode, const GenStftArgs& a, int num_cus, hipStrea
 hipError_t launch_gen_gl(int mode, const GenGlArgs& a, int num_cus, hipStream_t stream);      // mode 0 init, 1 first iteration, 2 iteration
 hipError_t launch_gen_env(const float* win, float* env, const GenGeom& g, int T, int L, hipStream_t stream);  // env[p] = sum_t w[j]^2, once per call
 hipError_t launch_gen_fold(const float* frames, const float* env, float* out, const GenGeom& g, int B, int T, int L, size_t out_stride,
-                           hipStream_t stream, const float* prev = nullptr, float* dout = nullptr, float mom = 0.f);  // L output samples per clip
+                           hipStream_t stream, const float* prev = nullptr, float* dout = nullptr, float mom = 0.f,
+                           const float* row_scale = nullptr);  // L output samples per clip; dout = (x - mom prev) * row_scale[2 b]
 hipError_t launch_gen_pack(const void* bft, void* frames, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_unpack(const void* frames, void* bft, bool complex_, int B, int F, int T, int fs, hipStream_t stream);
 hipError_t launch_gen_mel(const float* mag, float* mel_tm, const float* band_wt, const int* band_lo, const int* band_len, long long nframes,
@@ -292,6 +309,7 @@ struct FamGlArgs {
   const float* x_prev;   // mode 2:     x_{k-1}
   size_t audio_stride;
   float* frames;         // [B*T][fpitch] windowed, scaled synthesis frames, window sample j at fshift + j (GenGeom::fpitch / fshift)
+  const float* row_scale;  // [B][2] or null (see GlArgs)
   int fpitch, fshift;
   const cf* tw1;         // [21][h]      g(n')^k1
   const cf* twa;         // [ra-1][rb]   W_h^{i p} at [p - 1][i]: the lanes of a wave (consecutive i) read consecutive entries (round 5; [rb][ra-1] until
