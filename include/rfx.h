@@ -164,8 +164,8 @@ int rfx_stft_frames(const rfx_plan* plan, int Lw);
  * Where the reference itself stops being scale-free, this library follows the reference, not the scale: its stopping rule is
  * absolute (loss < 1e-5, |change| < 1e-8: tiny spectrograms stop after one step - reproduced), the bins no filter reaches keep
  * their U[0,1) start whatever max_value is (reproduced), and below |a| = 1e-8 in the input's units the `+ 1e-16` guard becomes
- * visible: there this library's guard, rsq(|a|^2 + 1e-32), differs from the reference's 1 / (|a| + 1e-16) by up to a factor of
- * two in the length of the phase factor (never in its direction; exactly 0 for a = 0 in both). */
+ * visible: there this library's guard, rsq(|a|^2 + 1e-32), differs from the reference's 1 / (|a| + 1e-16) by up to 41 %
+ * (at |a| = 1e-16) in the LENGTH of the phase factor - never in its direction, and it is exactly 0 for a = 0 in both. */
 typedef struct {
   uint32_t struct_size;
   uint32_t flags;           /* must be 0 */

@@ -164,13 +164,29 @@ __global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __res
     }
   }
   __syncthreads();
+  // The level is the count of v with ratio < thr[v] (thr descending).  Rounds 1-5 found it with an eight-step binary search: eight
+  // DEPENDENT LDS reads per pixel, which is what kept this kernel at half its byte bound.  Round 6: the table is a power curve
+  // (image_util.py:32-38: level = 255 - 255 ratio^power), so the level is ESTIMATED with two transcendentals from an exponent
+  // fitted to the table itself (no new argument: any table works), and four INDEPENDENT reads around the estimate settle it: the
+  // thresholds remain the judge, bit for bit - if the window does not bracket the answer (never seen for the reference's
+  // curves: the estimate is off by at most one level) the binary search runs.
+  const float t128 = thr_s[128];  // 255 - 255 t^p = 128  =>  p = log2(127 / 255) / log2(t)
+  const float pw = (t128 > 0.f && t128 < 1.f) ? __fdividef(-1.0056668f, __log2f(t128)) : 0.25f;
   auto quantise = [&](float x) {
     const float ratio = __fdiv_rn(x, mx);
-    int lo = 0, hi = 255;  // count of v with ratio < thr[v] (thr descending): binary search, 8 steps
+    const float est = 255.f - 255.f * __builtin_amdgcn_exp2f(pw * __builtin_amdgcn_logf(ratio));  // v_log_f32 / v_exp_f32 (NaN for a negative or NaN ratio)
+    int w = (int)est - 2;  // (a NaN converts to 0)
+    w = w < 0 ? 0 : (w > 251 ? 251 : w);
+    const bool c0 = ratio < thr_s[w], c1 = ratio < thr_s[w + 1], c2 = ratio < thr_s[w + 2], c3 = ratio < thr_s[w + 3];
+    int lo = w + (int)c0 + (int)c1 + (int)c2 + (int)c3;
+    if (!((c0 || w == 0) && (!c3 || w == 251))) {  // the window missed: the search of rounds 1-5
+      int hi = 255;
+      lo = 0;
 #pragma unroll
-    for (int step = 0; step < 8; ++step) {
-      const int mid = (lo + hi) >> 1;
-      if (ratio < thr_s[mid]) lo = mid + 1; else hi = mid;
+      for (int step = 0; step < 8; ++step) {
+        const int mid = (lo + hi) >> 1;
+        if (ratio < thr_s[mid]) lo = mid + 1; else hi = mid;
+      }
     }
     return (unsigned)lo;
   };
