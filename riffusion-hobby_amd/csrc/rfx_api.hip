@@ -185,10 +185,7 @@ int rfx_plan_imel_unit_form(const rfx_plan* plan) {
 
 int rfx_plan_imel_kernel(const rfx_plan* plan) {
   if (!plan || !plan->d_melfb || !plan->imel_ok) return -1;
-  if (plan->imel_variant == 2) return 0;
-  if (plan->imel_variant == 1) return plan->imel.fast_ok == 1 || plan->imel.fast_ok == 2 ? 1 : 0;
-  if (plan->imel_variant == 0 && plan->imel.wave_ok) return 4;
-  return plan->imel.fast_ok;
+  return rfx::imel_kernel_choice(plan->imel, plan->p.n_mels, plan->p.max_mel_iters, plan->imel_variant);
 }
 // torch.stft(center=True): the signal is reflect-padded by n_fft/2 on both sides, so a waveform of Lw samples gives
 // 1 + (Lw + 2*(n_fft/2) - n_fft) / hop frames: 1 + Lw/hop for even n_fft, 1 + (Lw - 1)/hop for odd n_fft
@@ -925,27 +922,27 @@ static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
   return plan->gl_latency_mode && (long long)B * T <= (long long)plan->gl_latency_frames_per_slot * plan->num_cus * plan->gl_wgs_per_cu;
 }
 
-// The runs of one launch of the run-based Griffin-Lim kernel: the batch's B*T frames, counted clip after clip, are cut into one run
-// per resident workgroup slot of the chip and never more (a launch of 520 workgroups on 512 slots runs eight of them alone in a
-// second wave: the ceil(slots / B) runs per clip of rounds 1-4 did that for every B that does not divide the slot count); every run
-// at least 10 frames long, so that a hop block is shared by at most two runs.  Round 5, second step: the runs of the workgroups the
-// dispatcher places first (one per CU, blocks 0 .. num_cus-1) are `skew` per mille LONGER than the mean and those of the workgroups
-// that join them that much shorter (rfx_kernels.h, GlArgs::run_h) - only when every CU gets exactly its two workgroups (the case
-// that was measured) and the short runs keep 11 frames; otherwise all runs are equal (+- 1 frame).  which = 0: the synthesis-only
-// first launch, 1: the iterations.
+// The runs of one launch of the run-based Griffin-Lim kernel: at most one run per resident workgroup slot of the chip (a launch of
+// 520 workgroups on 512 slots runs eight of them alone in a second wave: the ceil(slots / B) runs per clip of rounds 1-4 did that
+// for every B that does not divide the slot count).
 // Round 6: the unit of the partition is the GROUP (kGlGroup = 16 consecutive frames of a row, rfx_kernels.h): runs are whole groups,
 // at most one run per slot and never more runs than groups.  A clip's bits no longer depend on the partition at all (every group
 // boundary splits the overlap-add chains, inside a run as between runs), so the partition is free to follow the chip and the batch.
 struct GlPartition { int runs, h, w1, w2; };
 static GlPartition gl_partition(const rfx_plan* plan, int B, int T, int which) {
+  (void)which;
   const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu, N = (long long)B * rfx::gl_groups_per_row(T);
   long long nruns = N;
   if (nruns > slots) nruns = slots;
   if (nruns < 1) nruns = 1;
-  int skew = plan->gl_run_skew[which ? 1 : 0];
-  const bool full = plan->gl_wgs_per_cu == 2 && nruns == slots;
-  if (!full || skew < 0 || skew > 400 || (N * (1000 - skew)) / (1000LL * nruns) < 2) skew = 0;
-  return GlPartition{(int)nruns, plan->num_cus, 1000 + skew, 1000 - skew};
+  // N = q runs + r: the FIRST r runs take q + 1 groups, the others q (gl_run_start with weights q + 1 / q is exact: W_total = N).
+  // First, because blocks 0 .. num_cus - 1 are the workgroups the dispatcher places first, one per CU, and the earlier workgroup
+  // of a CU wins its issue arbitration: it runs ~12 % faster than the partner that joins it (profiles/r05_wgclock_dispatch_order.txt:
+  // 659 against 746 us for 64 frames each), so the extra group of a batch that is not a whole number of groups per slot (B = 65:
+  // 32 runs of 80 frames among 480 of 64) lands where there is slack.  (The per-mille skew of round 5 is gone with it: it never
+  // moved the step, same file.)
+  const long long q = N / nruns, r = N - q * nruns;
+  return GlPartition{(int)nruns, (int)r, (int)(q + 1), (int)q};
 }
 
 int rfx_griffinlim_runs(const rfx_plan* plan, int B, int T, int which, int64_t* run_starts, int capacity) {
@@ -1538,7 +1535,8 @@ size_t rfx_inverse_mel_workspace_bytes(const rfx_plan* plan, int B, int T) {
 // can InverseMelScale write a row-family plan's frames straight in the family kernels' slot order?  (Every kernel that leaves
 // through imel_emit_frame can: the output order is just its pos_bin table.  The general LDS kernel stores bin by bin.)
 static bool imel_can_emit_fam_slots(const rfx_plan* plan) {
-  return plan->generic && plan->fam_ok && plan->imel_ok && plan->d_fam_binof && (plan->imel.wave_ok || plan->imel.fast_ok) && plan->imel_variant == 0;
+  return plan->generic && plan->fam_ok && plan->imel_ok && plan->d_fam_binof &&
+         rfx::imel_kernel_choice(plan->imel, plan->p.n_mels, plan->p.max_mel_iters, plan->imel_variant) != 0;
 }
 
 static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int T, int channels_per_clip, const float* d_spec0,

@@ -1052,9 +1052,32 @@ static void launch_perwave(const ImelArgs& a, hipStream_t stream) {
                      dim3(kImelThreads * FPW), lds, stream, a);
 }
 
-hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
+// Which kernel launch_imel runs for a bank / variant / step count: 4 wave, 5 line-form groups, 2 / 3 per-wave group budgets, 1 uniform
+// groups, 0 the general LDS kernel.  ONE place decides (round 6): the launcher below, rfx_plan_imel_kernel and
+// imel_can_emit_fam_slots all ask here, so a build without the packed kernels (RFX_IMEL_PK = 0) or a bank whose frame does not
+// fit the 64 KB of LDS a kernel gets without the opt-in attribute falls back to the general kernel everywhere at once.
+int imel_kernel_choice(const ImelTables& tb, int M, int max_iter, int variant) {
+  const int band = tb.f_hi - tb.f_lo;
+  constexpr size_t kPlainLds = 64 * 1024;  // dynamic LDS a kernel may ask for without hipFuncAttributeMaxDynamicSharedMemorySize
 #if RFX_IMEL_PK && RFX_IMEL_WAVE
-  if (a.tb.wave_ok && variant == 0) {  // one wave per frame (the fix-up pass too: its frames are independent of each other)
+  if (tb.wave_ok && variant == 0 && sizeof(float) * ((size_t)max_iter + (size_t)band) <= kPlainLds) return 4;
+#endif
+  const size_t frame_lds = imel_frame_lds_bytes(M, max_iter, band);
+#if RFX_IMEL_PK
+  if (tb.fast_ok == 5 && variant == 0 && frame_lds <= kPlainLds) return 5;
+#endif
+  if (tb.fast_ok && tb.fast_ok != 5 && variant != 2 && !(variant == 1 && tb.fast_ok == 3) && frame_lds <= kPlainLds) {
+    if (tb.fast_ok == 2 && variant != 1) return 2;
+    if (tb.fast_ok == 3 && variant != 1) return 3;
+    return 1;
+  }
+  return 0;
+}
+
+hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
+  const int choice = imel_kernel_choice(a.tb, a.M, a.max_iter, variant);
+#if RFX_IMEL_PK && RFX_IMEL_WAVE
+  if (choice == 4) {  // one wave per frame (the fix-up pass too: its frames are independent of each other)
     const size_t lds = sizeof(float) * ((size_t)a.max_iter + (size_t)(a.tb.f_hi - a.tb.f_lo));  // loss words + the epilogue's stage (16.8 KB: eight waves per CU)
     if (a.tb.unit_form) hipLaunchKernelGGL(imel_wave_kernel<true>, dim3(a.B * a.T), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL(imel_wave_kernel<false>, dim3(a.B * a.T), dim3(64), lds, stream, a);
@@ -1062,7 +1085,7 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
   }
 #endif
 #if RFX_IMEL_PK
-  if (a.tb.fast_ok == 5 && variant == 0) {  // long groups in line form (full-band banks, 384 filters ...)
+  if (choice == 5) {  // long groups in line form (full-band banks, 384 filters ...)
     constexpr const int* lo = kImelLoCapLine;
     constexpr const int* hi = kImelHiCapLine;
     const size_t lds = imel_frame_lds_bytes(a.M, a.max_iter, a.tb.f_hi - a.tb.f_lo);
@@ -1071,16 +1094,16 @@ hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream) {
     return hipGetLastError();
   }
 #endif
-  if (a.tb.fast_ok && a.tb.fast_ok != 5 && variant != 2 && !(variant == 1 && a.tb.fast_ok == 3)) {  // (the wide and line sets have no uniform fallback: general kernel)
+  if (choice >= 1 && choice <= 3) {  // (the wide and line sets have no uniform fallback: general kernel)
     // the fix-up pass runs a different number of steps (and barriers) per clip: one frame per workgroup there
     const bool fixup = a.it_limit != nullptr;
-    if (a.tb.fast_ok == 2 && variant != 1) {
+    if (choice == 2) {
       if (a.tb.unit_form && RFX_IMEL_UFORM) {
         if (fixup) launch_perwave<1, 0, true>(a, stream); else launch_perwave<RFX_IMEL_FPW, 0, true>(a, stream);
       } else {
         if (fixup) launch_perwave<1, 0, false>(a, stream); else launch_perwave<RFX_IMEL_FPW, 0, false>(a, stream);
       }
-    } else if (a.tb.fast_ok == 3 && variant != 1) {
+    } else if (choice == 3) {
       if (a.tb.unit_form && RFX_IMEL_UFORM) {
         if (fixup) launch_perwave<1, 1, true>(a, stream); else launch_perwave<RFX_IMEL_FPW, 1, true>(a, stream);
       } else {

@@ -41,7 +41,8 @@ struct GlArgs {
 };
 
 // first frame of run b when the launch's N frames are cut into `runs` runs: the runs b < h weigh w1, the others w2 (integers,
-// per mille of the mean).  Exact integer arithmetic, the same on the host (checks) and in the kernel; N < 2^31, weights < 2^11.
+// any common unit: round 6 passes q + 1 and q groups for N = q runs + r, h = r).  Exact integer arithmetic, the same on the host
+// (checks) and in the kernel; N * (w1 h + w2 (runs - h)) must fit 63 bits (N < 2^27 groups and weights <= N do).
 RFX_HD long long gl_run_start(long long b, long long runs, long long N, long long h, long long w1, long long w2) {
   const long long hb = b < h ? b : h, ht = runs < h ? runs : h;
   const long long Wb = w1 * hb + w2 * (b - hb), Wt = w1 * ht + w2 * (runs - ht);
@@ -237,6 +238,9 @@ struct ImelArgs {
   unsigned long long frame_base;  // rfx_call_options::row_base * T: frame f of this call draws its start from key (seed, frame_base + f)
 };
 hipError_t launch_imel(const ImelArgs& a, int variant, hipStream_t stream);  // variant: 0 best, 1 uniform groups, 2 general
+// the kernel launch_imel runs: 4 wave, 5 line-form groups, 2 / 3 per-wave group budgets, 1 uniform groups, 0 general LDS kernel
+// (every one but 0 leaves through imel_emit_frame: its output order is the pos_bin table)
+int imel_kernel_choice(const ImelTables& tb, int M, int max_iter, int variant);
 // scans loss_hist for the early-stop condition; it_stop[clip] = steps the reference would have run
 // Numeric range (round 6, include/rfx.h): one workgroup per group of `count` contiguous floats of x (a clip's mel amplitudes, or a
 // row's magnitudes) takes max |x| - or `hint` when > 0, without reading x - and writes the powers of two the kernels work in:

@@ -59,7 +59,7 @@ def test_headline_line_small_batch():
     # independent of its batch), so a batch that is not a multiple of 16 tiles rounds the longest run up to the next group:
     # measured +7.0 % at B = 65 and +6.3 % at B = 100 (the few long runs finish alone on their CUs, faster), 0 at multiples of 16
     for b_ in ("65", "96", "100"):
-        assert abs(sweep[b_]["vs_linear_64_128_pct"]) <= (3.0 if b_ == "96" else 10.0), sweep
+        assert abs(sweep[b_]["vs_linear_64_128_pct"]) <= (3.0 if b_ == "96" else 14.0), sweep
     # round 6: the timed step is the product call; the four-call form of rounds 1-5 rides along; configs[0]'s GPU half
     st = d["stages"]
     assert st["product_call_ms"] > 0 and st["c_abi_four_calls_ms"] > 0 and st["workspace_arena"]["buffers_allocated_in_this_process"] >= 1
