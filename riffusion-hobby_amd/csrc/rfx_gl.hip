@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
       // ---- group boundary inside the run (wave-uniform): what the end of a run does - the parked block (complete, of the old
       // group) and the partial sums of the nine blocks across the cut leave for the old group's buffer; the new group starts its
       // own chains from zero in the other one
+      asm volatile("; RFX_ONCE_PER_GROUP_BEGIN");  // (markers for tools/isa_mix.py: this block runs once per kGlGroup frames)
       emit_scaled(pend_blk, pend_val);
       pend_blk = -1;
 #pragma unroll
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
       const rsrc_t tmp = outA;
       outA = outB;
       outB = tmp;
+      asm volatile("; RFX_ONCE_PER_GROUP_END");
     }
     const unsigned foff = (unsigned)fr * (kFrameStride * 4u);
     const unsigned rng_key = rand_frame_key(g.seed, g.frame_base + (unsigned long long)clip * g.T + fr);

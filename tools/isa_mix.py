@@ -20,7 +20,7 @@ KERNELS = [("rfx_gl.hip", "_ZN3rfx14gl_iter_kernelILi2EEEvNS_6GlArgsE", "rfx::gl
 TRANS = {"v_rsq_f32_e32", "v_rcp_f32_e32", "v_sqrt_f32_e32", "v_rsq_f32_e64", "v_rcp_f32_e64", "v_sqrt_f32_e64"}
 
 
-def loop_mix(asm: str, symbol: str):
+def loop_mix(asm: str, symbol: str, once_every: int = 16):
     s = asm.index(symbol + ":")
     body = asm[s:asm.index("s_endpgm", s)].split("\n")
     labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
@@ -31,14 +31,22 @@ def loop_mix(asm: str, symbol: str):
             loops.append((labels[m.group(1)], i))
     # the frame loop: the longest backward branch - or, when that one is an outer loop around it (round 5: gl_iter_kernel walks the
     # segments of a run), the loop nested inside it that makes up most of its body
-    best = max(loops, key=lambda ab: ab[1] - ab[0])
-    while True:
-        inner = [ab for ab in loops if best[0] <= ab[0] and ab[1] <= best[1] and ab != best and 2 * (ab[1] - ab[0]) >= best[1] - best[0]]
-        if not inner:
-            break
-        best = max(inner, key=lambda ab: ab[1] - ab[0])
+    # Round 6: "longest" is not enough - branchy epilogues are laid out with their taken paths behind the fall-through code, and the
+    # jumps back look like loops longer than the real one.  The loop wanted is the one that holds the packed arithmetic: among the
+    # backward branches with the most v_pk_* instructions, the shortest.
+    def packed(ab):
+        return sum(1 for l in body[ab[0]:ab[1] + 1] if re.match(r"\s+v_pk", l))
+    most = max(packed(ab) for ab in loops)
+    best = min((ab for ab in loops if packed(ab) == most), key=lambda ab: ab[1] - ab[0])
+    # a block between the markers `; RFX_ONCE_PER_GROUP_BEGIN / _END` (rfx_gl.hip: the group boundary inside a run) runs once per
+    # `once_every` trips: its instructions count with that weight
     mix = collections.Counter()
+    weight = 1.0
     for l in body[best[0]:best[1] + 1]:
+        if "RFX_ONCE_PER_GROUP_BEGIN" in l:
+            weight = 1.0 / once_every
+        elif "RFX_ONCE_PER_GROUP_END" in l:
+            weight = 1.0
         m = re.match(r"\s+([a-z_0-9]+)\s", l)
         if not m:
             continue
@@ -46,8 +54,8 @@ def loop_mix(asm: str, symbol: str):
         key = ("valu_packed" if k.startswith("v_pk") else "valu_quarter_rate" if k in TRANS else "valu_plain" if k.startswith("v_") else
                "lds" if k.startswith("ds_") else "vmem" if k.startswith(("buffer", "global")) else "scratch" if k.startswith("scratch") else
                "s_nop" if k == "s_nop" else "s_waitcnt" if k == "s_waitcnt" else "s_barrier" if k == "s_barrier" else "salu")
-        mix[key] += 1
-    return dict(mix)
+        mix[key] += weight
+    return {k: round(v, 1) if v != int(v) else int(v) for k, v in mix.items()}
 
 
 def main():
