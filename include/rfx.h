@@ -129,6 +129,12 @@ int rfx_griffinlim_runs(const rfx_plan* plan, int B, int T, int which, int64_t* 
 /* the arithmetic behind it, callable without a plan or a GPU (tests): first frame of run b of `runs` over n_frames frames when
  * the first h runs weigh w1 and the others w2 (per mille of the mean run length) */
 int64_t rfx_debug_run_start(int64_t b, int64_t runs, int64_t n_frames, int64_t h, int64_t w1, int64_t w2);
+/* the partition rfx_griffinlim_runs reports, for a chip with `slots` resident workgroup slots, without a plan or a GPU (tests):
+ * runs are whole groups of 16 frames of a row (round 6), the first N mod runs of them one group longer */
+int rfx_debug_gl_partition(int slots, int B, int T, int64_t* run_starts, int capacity);
+/* the two internal exponents of "Numeric range" above for a largest magnitude max_abs (mel_units != 0: max_abs is a mel amplitude,
+ * the Griffin-Lim exponent is then taken for max(max_abs, 1) x 2), without a GPU (tests) */
+int rfx_debug_range_exponents(float max_abs, int mel_units, int* sgd_exponent, int* gl_exponent);
 /* frames torch.stft(center=True, pad_mode="reflect") makes of Lw samples: 1 + (Lw + 2*(n_fft/2) - n_fft) / hop, i.e.
  * 1 + Lw/hop for even n_fft and 1 + (Lw-1)/hop for odd n_fft; 0 when Lw <= n_fft/2 (the reference raises there).
  * Every forward entry point below produces exactly this many frames. */

@@ -929,9 +929,8 @@ static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
 // at most one run per slot and never more runs than groups.  A clip's bits no longer depend on the partition at all (every group
 // boundary splits the overlap-add chains, inside a run as between runs), so the partition is free to follow the chip and the batch.
 struct GlPartition { int runs, h, w1, w2; };
-static GlPartition gl_partition(const rfx_plan* plan, int B, int T, int which) {
-  (void)which;
-  const long long slots = (long long)plan->num_cus * plan->gl_wgs_per_cu, N = (long long)B * rfx::gl_groups_per_row(T);
+static GlPartition gl_partition_for(long long slots, int B, int T) {
+  const long long N = (long long)B * rfx::gl_groups_per_row(T);
   long long nruns = N;
   if (nruns > slots) nruns = slots;
   if (nruns < 1) nruns = 1;
@@ -944,6 +943,10 @@ static GlPartition gl_partition(const rfx_plan* plan, int B, int T, int which) {
   const long long q = N / nruns, r = N - q * nruns;
   return GlPartition{(int)nruns, (int)r, (int)(q + 1), (int)q};
 }
+static GlPartition gl_partition(const rfx_plan* plan, int B, int T, int which) {
+  (void)which;
+  return gl_partition_for((long long)plan->num_cus * plan->gl_wgs_per_cu, B, T);
+}
 
 int rfx_griffinlim_runs(const rfx_plan* plan, int B, int T, int which, int64_t* run_starts, int capacity) {
   if (!plan || B <= 0 || T < 2 || plan->generic) return 0;
@@ -955,6 +958,25 @@ int rfx_griffinlim_runs(const rfx_plan* plan, int B, int T, int which, int64_t* 
 
 int64_t rfx_debug_run_start(int64_t b, int64_t runs, int64_t n_frames, int64_t h, int64_t w1, int64_t w2) {
   return rfx::gl_run_start(b, runs, n_frames, h, w1, w2);
+}
+
+int rfx_debug_gl_partition(int slots, int B, int T, int64_t* run_starts, int capacity) {
+  if (slots <= 0 || B <= 0 || T < 2) return 0;
+  const GlPartition p = gl_partition_for(slots, B, T);
+  if (run_starts)
+    for (int b = 0; b <= p.runs && b < capacity; ++b) run_starts[b] = rfx::gl_run_start_frame(b, p.runs, B, T, p.h, p.w1, p.w2);
+  return p.runs;
+}
+
+int rfx_debug_range_exponents(float max_abs, int mel_units, int* sgd_exponent, int* gl_exponent) {
+  if (!sgd_exponent || !gl_exponent) return fail(RFX_ERR_INVALID, "rfx_debug_range_exponents: null argument");
+  int k = 0;
+  if (max_abs > 0.f) {
+    if (max_abs < __builtin_inff()) (void)frexpf(max_abs, &k);
+    else k = 129;
+  }
+  rfx::range_exponents(k, mel_units, sgd_exponent, gl_exponent);
+  return RFX_OK;
 }
 
 int rfx_griffinlim_form(const rfx_plan* plan, int B, int T) {

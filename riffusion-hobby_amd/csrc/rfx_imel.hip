@@ -1151,18 +1151,16 @@ __global__ void __launch_bounds__(64) range_finish_kernel(const unsigned* __rest
     if (mx < __builtin_inff()) (void)frexpf(mx, &k);
     else k = 129;
   }
+  int e, j;
+  range_exponents(k, mel_units, &e, &j);
   if (imel_scale) {
-    // the clip's largest target near 2^-35 of the clamp's upper bound (2^-60 for max_value = 30e6, as in rounds 2-5); never above
-    // 2^-30: the untouched bins start at U[0, 1) in the reference's units whatever the targets are
-    int e = k + 35;
-    e = e < 30 ? 30 : (e > 126 ? 126 : e);
+    // e = max(k + 35, 30): the clip's largest target near 2^-35 of the clamp's upper bound (2^-60 for max_value = 30e6, as in rounds
+    // 2-5); never above 2^-30: the untouched bins start at U[0, 1) in the reference's units whatever the targets are
     imel_scale[2 * g] = ldexpf(1.f, -e);
     imel_scale[2 * g + 1] = ldexpf(1.f, e);
   }
   if (gl_scale) {
-    const int ks = mel_units ? (k > 0 ? k : 0) + 1 : k;
-    int j = ks - 26;  // the row's largest magnitude near 2^25: what 30e6 gives unscaled (j = 0)
-    j = j < -100 ? -100 : (j > 100 ? 100 : j);
+    // j = ks - 26: the row's largest magnitude near 2^25, what 30e6 gives unscaled (j = 0); ks = k, or max(k, 0) + 1 in mel units
     const float eps2 = fmaxf(ldexpf(1e-32f, -2 * j), 1.17549435e-38f);  // never zero: 0 * rsq(0 + 0) would be NaN where the reference gives 0
     for (int r = 0; r < rows; ++r) {
       gl_scale[2 * ((size_t)g * rows + r)] = ldexpf(1.f, -j);

@@ -247,6 +247,15 @@ int imel_kernel_choice(const ImelTables& tb, int M, int max_iter, int variant);
 //   imel_scale[g] = {2^-e, 2^e}, e = max(k + 35, 30) for max in [2^(k-1), 2^k)     (nullable)
 //   gl_scale[g * rows + r] = {2^-j, eps^2}, j = ks - 26, ks = k, or max(k, 0) + 1 when `mel_units` (the SGD's untouched bins keep
 //   their U[0,1) start: a row's magnitudes reach 1 whatever the mel amplitudes are)                         (nullable)
+// the arithmetic of it, shared by the kernel and rfx_debug_range_exponents (tests without a GPU): k with mx in [2^(k-1), 2^k)
+// (0 for mx == 0 or NaN, 129 for +Inf) -> the SGD exponent e and the Griffin-Lim exponent j
+RFX_HD void range_exponents(int k, int mel_units, int* e, int* j) {
+  int ee = k + 35;
+  *e = ee < 30 ? 30 : (ee > 126 ? 126 : ee);
+  const int ks = mel_units ? (k > 0 ? k : 0) + 1 : k;
+  int jj = ks - 26;
+  *j = jj < -100 ? -100 : (jj > 100 ? 100 : jj);
+}
 // keys: [groups] scratch words.  groups <= 65535 per launch (grid y).
 hipError_t launch_range_scale(const float* x, size_t count, int groups, float hint, unsigned* keys, float* imel_scale, float* gl_scale, int rows,
                               int mel_units, hipStream_t stream);

@@ -91,6 +91,8 @@ SIGNATURES: T.Dict[str, T.Tuple[T.Any, T.List[T.Any]]] = {
     "rfx_griffinlim_form": (c_int, [c_void_p, c_int, c_int]),
     "rfx_griffinlim_runs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int]),
     "rfx_debug_run_start": (ctypes.c_int64, [ctypes.c_int64] * 6),
+    "rfx_debug_gl_partition": (c_int, [c_int, c_int, c_int, c_void_p, c_int]),
+    "rfx_debug_range_exponents": (c_int, [c_float, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "rfx_stft_frames": (c_int, [c_void_p, c_int]),
     "rfx_plan_imel_kernel": (c_int, [c_void_p]),
     "rfx_plan_imel_unit_form": (c_int, [c_void_p]),
