@@ -84,11 +84,8 @@ struct EventList {
 };
 }  // namespace
 
-#ifndef RFX_GL_RUN_SKEW
-#define RFX_GL_RUN_SKEW 0
-#endif
-#ifndef RFX_GL_RUN_SKEW0
-#define RFX_GL_RUN_SKEW0 0
+#ifndef RFX_FWD_RUN_SKEW
+#define RFX_FWD_RUN_SKEW 170  // per mille: 74 / 54 frames instead of 64 / 64; -4.3 % on the forward kernel (profiles/r06_forward_skew.txt)
 #endif
 
 struct rfx_plan {
@@ -97,11 +94,6 @@ struct rfx_plan {
   int num_cus;
   int n_stft;
   int gl_wgs_per_cu = 1;    // resident Griffin-Lim workgroups per CU on this device (occupancy query at creation)
-  // how much longer the run of a first-dispatched workgroup is than the mean (per mille; its CU partner's is that much shorter):
-  // rfx_kernels.h GlArgs::run_w1.  [0]: the synthesis-only launch (MODE 0), [1]: the iterations.  0 = equal runs, the default:
-  // a skew of 100 makes the pair of a CU finish together and gains 0.4 % (the kernel is power-bound: DESIGN.md 4.1,
-  // profiles/r05_wgclock_dispatch_order.txt); only -DRFX_ABLATION builds can set it (RFX_GL_SKEW / RFX_GL_SKEW0).
-  int gl_run_skew[2] = {RFX_GL_RUN_SKEW0, RFX_GL_RUN_SKEW};
   int imel_variant = 0;     // debugging override read once at creation: 0 = best, 1 = uniform groups, 2 = general
   unsigned long long* timing = nullptr;  // RFX_TIMING builds only
   cf* d_tw1 = nullptr;      // [21][441]
@@ -130,6 +122,7 @@ struct rfx_plan {
   unsigned fwd_kb_mask = 0;
   int fwd_prod_arr = 0;
   int fwd_packed_off = 0;          // ints into d_slot_idx where the packed tables start (0: none)
+  int fwd_run_skew = RFX_FWD_RUN_SKEW;  // per mille of the run length the first-dispatched workgroups of the forward kernel take on top (RFX_FWD_SKEW in ablation builds)
   int fwd_run_cap = 64;            // longest run of frames one workgroup of the product-form kernel walks (RFX_FWD_RUN, read at creation)
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
   bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
@@ -327,8 +320,6 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   }
   pl->gl_wgs_per_cu = gl_blocks_per_cu();
   if (const char* e = abl_env("RFX_GL_WGS_PER_CU")) pl->gl_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 1;
-  if (const char* e = abl_env("RFX_GL_SKEW")) pl->gl_run_skew[1] = atoi(e);
-  if (const char* e = abl_env("RFX_GL_SKEW0")) pl->gl_run_skew[0] = atoi(e);
   pl->imel_variant = abl_env("RFX_IMEL_GENERAL") ? 2 : abl_env("RFX_IMEL_UNIFORM") ? 1 : abl_env("RFX_IMEL_NO_PAIR") ? 3 : 0;  // 3: best one-frame kernel
   // which Griffin-Lim device form a call takes: the options of rfx_plan_create_ex decide; the environment (read here, once)
   // only changes what RFX_GL_FORM_AUTO / the default threshold mean, for experiments
@@ -746,6 +737,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
       }
       pl->fwd_unfused = abl_env("RFX_FWD_UNFUSED") != nullptr;
       if (const char* e = abl_env("RFX_FWD_RUN")) pl->fwd_run_cap = atoi(e) > 0 ? atoi(e) : 64;
+      if (const char* e = abl_env("RFX_FWD_SKEW")) pl->fwd_run_skew = atoi(e);
     }
     if (ok) {
       // one device blob: csr_w | csr_ptr | band_lo | bin_m0 | bin_w0 | bin_w1 | bin_pos | bin_pos2
@@ -1443,6 +1435,12 @@ static int mel_forward(const rfx_plan* plan, const float* d_wave, int B, int Lw,
     const int cap = plan->d_slot_tab ? plan->fwd_run_cap : 16;
     int fpb = (int)((frames + 2LL * plan->num_cus - 1) / (2LL * plan->num_cus));
     f.frames_per_block = fpb < 1 ? 1 : fpb > cap ? cap : fpb;
+    {  // unequal runs by dispatch order (StftMelArgs::run_skew), only in the shape it was measured in: one wave of workgroups, two per CU
+      const int chunks = (f.T + f.frames_per_block - 1) / f.frames_per_block;
+      const bool shape_ok = plan->d_slot_tab && chunks % 2 == 0 && chunks * f.frames_per_block == f.T && (long long)B * chunks == 2LL * plan->num_cus;
+      const int d = (int)((long long)f.frames_per_block * plan->fwd_run_skew / 1000);
+      f.run_skew = shape_ok && d > 0 && d < f.frames_per_block ? d : 0;
+    }
     RFX_HIP(launch_stft_mel(f, (hipStream_t)stream));
     return RFX_OK;
   }

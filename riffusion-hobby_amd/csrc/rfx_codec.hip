@@ -170,8 +170,11 @@ __global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __res
   // fitted to the table itself (no new argument: any table works), and four INDEPENDENT reads around the estimate settle it: the
   // thresholds remain the judge, bit for bit - if the window does not bracket the answer (never seen for the reference's
   // curves: the estimate is off by at most one level) the binary search runs.
-  const float t128 = thr_s[128];  // 255 - 255 t^p = 128  =>  p = log2(127 / 255) / log2(t)
-  const float pw = (t128 > 0.f && t128 < 1.f) ? __fdividef(-1.0056668f, __log2f(t128)) : 0.25f;
+  // thr[v] is the smallest ratio whose level is <= v: trunc(255 - 255 r^p) <= 128  <=>  r^p > 126 / 255, so p = log2(126 / 255) / log2(thr[128])
+  // (with 127 / 255 - the first version - p came out 1.1 % low, one pixel in 200 fell outside the window and most WAVES ran the
+  // search as well: 55 us instead of 48; tools/probe_encode.py)
+  const float t128 = thr_s[128];
+  const float pw = (t128 > 0.f && t128 < 1.f) ? __fdividef(-1.0170735f, __log2f(t128)) : 0.25f;
   auto quantise = [&](float x) {
     const float ratio = __fdiv_rn(x, mx);
     const float est = 255.f - 255.f * __builtin_amdgcn_exp2f(pw * __builtin_amdgcn_logf(ratio));  // v_log_f32 / v_exp_f32 (NaN for a negative or NaN ratio)

@@ -127,6 +127,7 @@ struct StftMelArgs {
   const int* band_lo;    // [Mpad] first bin of filter m's band (padding filters: 0)
   const int* band_len;   // [Mpad] bins in filter m's band (padding filters: 0)
   int B, T, Lw, frames_per_block;
+  int run_skew;          // stft_mel2_kernel: > 0 = the first-dispatched half of the grid walks runs this many frames longer, the other half as many shorter
   int M, Mpad;           // Mpad = M rounded up to 64
   int f_lo, f_hi;        // bins with a non-zero filterbank row: [f_lo, f_hi)
   // product form (stft_mel2_kernel; valid when slot_tab != nullptr): the thread that owns a bin's primary slot multiplies

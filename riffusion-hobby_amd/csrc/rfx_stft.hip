@@ -295,9 +295,23 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
   static_assert(!PK || (KBMASK == kKbMaskLow && NKB == 10), "the packed tables hold ten slots per thread");
 
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
-  const int clip = blockIdx.x / chunks;
-  const int f0 = (blockIdx.x - clip * chunks) * a.frames_per_block;
-  const int f1 = min(a.T, f0 + a.frames_per_block);
+  int clip = blockIdx.x / chunks;
+  int f0 = (blockIdx.x - clip * chunks) * a.frames_per_block;
+  int f1 = min(a.T, f0 + a.frames_per_block);
+  if (a.run_skew > 0) {
+    // Round 6: frames are independent here, so the runs need not be equal.  With exactly two workgroups per CU the blocks of the
+    // first half of the grid are the ones the dispatcher places first (one per CU); they win the CU's issue arbitration and finish
+    // early (profiles/r05_wgclock_dispatch_order.txt: the same frame engine in the Griffin-Lim kernel, 659 against 746 us), so they
+    // take `run_skew` frames more and their partners as many fewer: every clip's first chunks/2 runs are long ones (host: chunks
+    // even, T == chunks * frames_per_block, gridDim.x == 2 x CUs).
+    const int half = gridDim.x >> 1, hc = chunks >> 1;
+    const bool lng = (int)blockIdx.x < half;
+    const int idx = lng ? (int)blockIdx.x : (int)blockIdx.x - half;
+    clip = idx / hc;
+    const int c = idx - clip * hc, fl = a.frames_per_block + a.run_skew, fs = a.frames_per_block - a.run_skew;
+    f0 = lng ? c * fl : hc * fl + c * fs;
+    f1 = f0 + (lng ? fl : fs);
+  }
   const rsrc_t xin = make_rsrc(a.wave + (size_t)clip * a.Lw, (size_t)a.Lw * 4);
   const rsrc_t win = make_rsrc(a.win, kWin * 4);
   const rsrc_t slots = make_rsrc(a.slot_tab, 21 * kQPad * 8);
