@@ -1598,7 +1598,6 @@ static int inverse_mel_impl(const rfx_plan* plan, const float* d_mel, int B, int
   // numeric range: the power of two each clip's SGD state is held in (and, for the fused call, the Griffin-Lim rows' factors),
   // from the caller's hint or the clip's largest mel amplitude
   float* clip_scale = (float*)(ws + align_up((size_t)B * T * plan->p.max_mel_iters * sizeof(float), 256) + align_up((size_t)(B + 1) * sizeof(int), 256));
-  if (nclips > 65535) return fail(RFX_ERR_INVALID, "rfx_inverse_mel: more than 65535 clips in one call");
   RFX_HIP(launch_range_scale(d_mel, (size_t)channels_per_clip * plan->p.n_mels * T, nclips, opt.magnitude_hint, (unsigned*)(clip_scale + 2 * (size_t)nclips),
                              clip_scale, d_gl_row_scale, channels_per_clip, 1, stream));
   ImelArgs a;

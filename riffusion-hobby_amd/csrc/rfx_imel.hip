@@ -1176,8 +1176,11 @@ hipError_t launch_range_scale(const float* x, size_t count, int groups, float hi
     size_t chunks = (count + 256 * 64 - 1) / (256 * 64);  // ~64 values per thread
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(range_max_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), 0, stream, x, count, keys);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    for (int g0 = 0; g0 < groups; g0 += 65535) {  // (grid y is 16 bits wide)
+      const int n = groups - g0 < 65535 ? groups - g0 : 65535;
+      hipLaunchKernelGGL(range_max_kernel, dim3((unsigned)chunks, (unsigned)n), dim3(256), 0, stream, x + (size_t)g0 * count, count, keys + g0);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
   }
   hipLaunchKernelGGL(range_finish_kernel, dim3((groups + 63) / 64), dim3(64), 0, stream, keys, groups, hint, imel_scale, gl_scale, rows, mel_units);
   return hipGetLastError();

@@ -257,7 +257,7 @@ RFX_HD void range_exponents(int k, int mel_units, int* e, int* j) {
   int jj = ks - 26;
   *j = jj < -100 ? -100 : (jj > 100 ? 100 : jj);
 }
-// keys: [groups] scratch words.  groups <= 65535 per launch (grid y).
+// keys: [groups] scratch words
 hipError_t launch_range_scale(const float* x, size_t count, int groups, float hint, unsigned* keys, float* imel_scale, float* gl_scale, int rows,
                               int mel_units, hipStream_t stream);
 hipError_t launch_imel_scan(const float* loss_hist, int* it_stop, int* any_early, int nclips, int C, int T, int max_iter,

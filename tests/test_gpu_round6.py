@@ -61,6 +61,19 @@ def test_pcm_is_independent_of_chunking_and_sharding(stereo, width):
     assert _hip.call_options(3 * C).row_base == 3 * C
 
 
+@pytest.mark.parametrize("rate", [48000, 22050, 11025])
+def test_other_engines_are_independent_of_chunking_too(rate):
+    """The row-family (48 / 22.05 kHz) and generic (11.025 kHz) engines: per-frame kernels + a fold in fixed order were always
+    partition-free; with the global row in the key of the random starts their PCM is chunking-free as well."""
+    conv = _conv(False, iters=4, sample_rate=rate)
+    tiles = synthetic_tiles_u8(5, 512, 64, seed=rate)
+    whole = conv.audio_from_spectrogram_images(tiles, seed=11, tiles_per_call=5)
+    assert np.abs(whole.astype(np.int32)).max() > 30000
+    for per_call in (2, 1):
+        assert np.array_equal(conv.audio_from_spectrogram_images(tiles, seed=11, tiles_per_call=per_call), whole), (rate, per_call)
+    assert not np.array_equal(conv.audio_from_spectrogram_images(tiles, seed=12, tiles_per_call=5), whole)
+
+
 def test_float_waveforms_are_independent_of_chunking():
     """return_waveform=True (decode, rfx_waveform_from_mel_ex per chunk): bit-identical float waveforms for 9 tiles in chunks of 9 / 4 / 1."""
     conv = _conv(False, iters=6)
