@@ -941,18 +941,16 @@ def main():
     # ---- the one-tile-per-request case (reference server.py:152-164): uint8 tile in HBM -> int16 PCM on the host, one call
     latency = None
     if rank == 0:
-        from riffusion.spectrogram_image_converter import SpectrogramImageConverter
-
         latency = {}
         for name, stereo in (("mono", False), ("stereo", True)):
-            conv = SpectrogramImageConverter(SpectrogramParams(stereo=stereo, num_griffin_lim_iters=args.iters), device=str(dev))
+            conv1 = SpectrogramImageConverter(SpectrogramParams(stereo=stereo, num_griffin_lim_iters=args.iters), device=str(dev))
             one = tiles[:1]
             for r in range(3):
-                conv.audio_from_spectrogram_images(one, seed=r)
+                conv1.audio_from_spectrogram_images(one, seed=r)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for r in range(10):
-                conv.audio_from_spectrogram_images(one, seed=10 + r)
+                conv1.audio_from_spectrogram_images(one, seed=10 + r)
             latency[name + "_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
         latency["note"] = "SpectrogramImageConverter.audio_from_spectrogram_images on ONE 512x512 tile, D2H copy of the PCM included (small-batch Griffin-Lim kernels)"
 

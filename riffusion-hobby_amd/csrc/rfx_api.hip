@@ -1350,10 +1350,10 @@ size_t rfx_mel_workspace_bytes(const rfx_plan* plan, int B, int Lw) {
 static bool forward_has_frame_major(const rfx_plan* plan) { return plan->generic ? plan->fwd_ok : (plan->fwd_ok && !plan->fwd_unfused); }
 
 // rfx_mel_from_waveform, and the front half of rfx_image_from_waveform: there d_mel_out is null (no (B, M, T) copy is made),
-// *mel_tm_out receives the frame-major amplitudes and - where the kernel can take it on the fly - max_keys[clip / max_group] the
-// key of the maximum (*keys_done says whether it did)
+// *mel_tm_out receives the frame-major amplitudes and - where the kernel can take it on the fly - max_keys the keys of the maxima its
+// workgroups formed, *keys_per_row of them for every row, rows in order (0: it did not; up to T per row: image_keys_bytes)
 static int mel_forward(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_mel_out, void* d_workspace, size_t workspace_bytes,
-                       void* stream, float** mel_tm_out, unsigned* max_keys, int max_group, bool* keys_done) {
+                       void* stream, float** mel_tm_out, unsigned* max_keys, int max_group, int* keys_per_row) {
   if (!plan || !d_wave || !d_workspace || (!d_mel_out && !mel_tm_out)) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: null argument");
   if (!plan->d_melfb) return fail(RFX_ERR_INVALID, "rfx_mel_from_waveform: plan was created without a mel filterbank");
   if (workspace_bytes < rfx_mel_workspace_bytes(plan, B, Lw) || Lw <= plan->p.n_fft / 2)
@@ -1427,7 +1427,6 @@ static int mel_forward(const rfx_plan* plan, const float* d_wave, int B, int Lw,
     f.pk_seg = f.pk_at ? f.pk_pad + 2 * (size_t)kQPad : nullptr;
     f.max_keys = plan->d_slot_tab ? max_keys : nullptr;  // (the product-form kernel takes the maximum on the fly)
     f.max_group = max_group > 0 ? max_group : 1;
-    if (keys_done) *keys_done = f.max_keys != nullptr;
     if (mel_tm_out) *mel_tm_out = f.mel_tm;
     // runs of consecutive frames: every resident workgroup slot of the chip gets one run when the batch allows it (the
     // product-form kernel carries a sliding input window along a run), at most 64 frames, at least 1
@@ -1440,6 +1439,7 @@ static int mel_forward(const rfx_plan* plan, const float* d_wave, int B, int Lw,
       const bool shape_ok = plan->d_slot_tab && chunks % 2 == 0 && chunks * f.frames_per_block == f.T && (long long)B * chunks == 2LL * plan->num_cus;
       const int d = (int)((long long)f.frames_per_block * plan->fwd_run_skew / 1000);
       f.run_skew = shape_ok && d > 0 && d < f.frames_per_block ? d : 0;
+      if (keys_per_row) *keys_per_row = f.max_keys ? chunks : 0;
     }
     RFX_HIP(launch_stft_mel(f, (hipStream_t)stream));
     return RFX_OK;
@@ -1470,12 +1470,15 @@ int rfx_mel_from_waveform(const rfx_plan* plan, const float* d_wave, int B, int 
 
 // ---- spectrogram_image_from_audio's device half (spectrogram_image_converter.py:30-51: spectrogram_from_audio, then
 // image_util.image_from_spectrogram): waveforms -> mel amplitudes -> uint8 image without the (B, M, T) tensor in between
+// the forward kernel leaves one key per workgroup: at most one workgroup per frame
+static size_t image_keys_bytes(const rfx_plan* plan, int rows, int Lw) { return align_up((size_t)rows * stft_frames(plan, Lw) * sizeof(unsigned), 256); }
+
 size_t rfx_image_from_waveform_workspace_bytes(const rfx_plan* plan, int N, int stereo, int Lw) {
   if (!plan || N <= 0) return 0;
   const int C = stereo ? 2 : 1;
   const size_t mel_ws = rfx_mel_workspace_bytes(plan, N * C, Lw);
   if (!mel_ws) return 0;
-  size_t total = mel_ws + align_up((size_t)N * sizeof(unsigned), 256);
+  size_t total = mel_ws + image_keys_bytes(plan, N * C, Lw);
   if (!forward_has_frame_major(plan)) total += align_up((size_t)N * C * plan->p.n_mels * stft_frames(plan, Lw) * sizeof(float), 256);
   return total;
 }
@@ -1492,19 +1495,18 @@ int rfx_image_from_waveform(const rfx_plan* plan, const float* d_wave, int N, in
   const size_t mel_ws = rfx_mel_workspace_bytes(plan, B, Lw);
   unsigned* keys = reinterpret_cast<unsigned*>((char*)d_workspace + mel_ws);
   if (!forward_has_frame_major(plan)) {  // (dense-GEMM fall-back of a non-banded bank: the two calls, the tensor in the workspace)
-    float* mel = reinterpret_cast<float*>((char*)keys + align_up((size_t)N * sizeof(unsigned), 256));
+    float* mel = reinterpret_cast<float*>((char*)keys + image_keys_bytes(plan, B, Lw));
     if (int rc = rfx_mel_from_waveform(plan, d_wave, B, Lw, mel, d_workspace, mel_ws, stream)) return rc;
     return rfx_image_encode_u8(mel, N, M, T, stereo, d_thresholds255, d_clip_max, d_img_out, stream);
   }
-  RFX_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned) * (size_t)N, (hipStream_t)stream));
   float* mel_tm = nullptr;
-  bool keys_done = false;
-  if (int rc = mel_forward(plan, d_wave, B, Lw, nullptr, d_workspace, mel_ws, stream, &mel_tm, keys, C, &keys_done)) return rc;
+  int keys_per_row = 0;  // (round 6: one key per workgroup of the forward kernel, every one written by the launch: nothing to zero)
+  if (int rc = mel_forward(plan, d_wave, B, Lw, nullptr, d_workspace, mel_ws, stream, &mel_tm, keys, C, &keys_per_row)) return rc;
   // (a kernel that does not take the maximum on the fly: one pass over the frame-major amplitudes; their padding columns are zero
   // and mel amplitudes are not negative)
-  if (!keys_done) RFX_HIP(launch_clip_max(mel_tm, reinterpret_cast<float*>(keys), N, (size_t)C * T * plan->Mpad, false, (hipStream_t)stream));
-  RFX_HIP(launch_image_encode_tm(mel_tm, keys_done ? keys : nullptr, keys_done ? nullptr : reinterpret_cast<const float*>(keys), d_thresholds255,
-                                 d_img_out, d_clip_max, N, M, plan->Mpad, T, C, (hipStream_t)stream));
+  if (!keys_per_row) RFX_HIP(launch_clip_max(mel_tm, reinterpret_cast<float*>(keys), N, (size_t)C * T * plan->Mpad, false, (hipStream_t)stream));
+  RFX_HIP(launch_image_encode_tm(mel_tm, keys_per_row ? keys : nullptr, C * keys_per_row, keys_per_row ? nullptr : reinterpret_cast<const float*>(keys),
+                                 d_thresholds255, d_img_out, d_clip_max, N, M, plan->Mpad, T, C, (hipStream_t)stream));
   return RFX_OK;
 }
 

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(128) image_encode_kernel(const float* __restri
 // of 128 frames x 32 mel bins per channel: whole 128-byte lines in (32 floats of a frame), transposed in LDS, and out as 384
 // contiguous bytes per image row (twelve bytes per thread, whole lines).  Same quantiser as image_encode_kernel, bit for bit.
 constexpr int kEncTmT = 128, kEncTmM = 32, kEncTmPitch = kEncTmT + 4;  // LDS row = one mel bin's 128 frames (+4: 16-byte reads stay aligned, rows shift banks)
-__global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __restrict__ mel_tm, const unsigned* __restrict__ max_keys,
+__global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __restrict__ mel_tm, const unsigned* __restrict__ max_keys, int keys_per_image,
                                                              const float* __restrict__ clip_max_in, const float* __restrict__ thr,
                                                              uint8_t* __restrict__ img, float* __restrict__ clip_max_out, int M,
                                                              int Mpad, int T, int C) {
@@ -145,8 +145,15 @@ __global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __res
   thr_s[threadIdx.x] = threadIdx.x < 255 ? thr[threadIdx.x] : -__builtin_inff();
   const int t0 = blockIdx.x * kEncTmT, m0 = blockIdx.y * kEncTmM;
   const size_t n = blockIdx.z;
-  const float mx = max_keys ? key_value(max_keys[n]) : clip_max_in[n];
-  if (clip_max_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clip_max_out[n] = mx;
+  // the image's maximum: the largest of the keys the forward kernel's workgroups left for its rows (L2 hits), or a float
+  __shared__ unsigned key_s[4];
+  if (max_keys) {
+    unsigned k = 0;
+    for (int j = threadIdx.x; j < keys_per_image; j += 256) k = max(k, max_keys[n * keys_per_image + j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) k = max(k, (unsigned)__shfl_xor((int)k, o));
+    if ((threadIdx.x & 63) == 0) key_s[threadIdx.x >> 6] = k;
+  }
   // in: thread (frame r of 32, quad of four mel bins): four passes over the tile's 128 frames
   {
     const int mq = 4 * (threadIdx.x & 7), r0 = threadIdx.x >> 3;
@@ -164,6 +171,8 @@ __global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __res
     }
   }
   __syncthreads();
+  const float mx = max_keys ? key_value(max(max(key_s[0], key_s[1]), max(key_s[2], key_s[3]))) : clip_max_in[n];
+  if (clip_max_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clip_max_out[n] = mx;
   // The level is the count of v with ratio < thr[v] (thr descending).  Rounds 1-5 found it with an eight-step binary search: eight
   // DEPENDENT LDS reads per pixel, which is what kept this kernel at half its byte bound.  Round 6: the table is a power curve
   // (image_util.py:32-38: level = 255 - 255 ratio^power), so the level is ESTIMATED with two transcendentals from an exponent
@@ -273,10 +282,10 @@ hipError_t launch_image_encode(const float* mel, const float* clip_max, const fl
   hipLaunchKernelGGL(image_encode_kernel, dim3(bx < 1 ? 1 : bx, M, N), dim3(128), 0, s, mel, clip_max, thr, img, M, T, C);
   return hipGetLastError();
 }
-hipError_t launch_image_encode_tm(const float* mel_tm, const unsigned* max_keys, const float* clip_max_in, const float* thr, uint8_t* img,
-                                  float* clip_max_out, int N, int M, int Mpad, int T, int C, hipStream_t s) {
+hipError_t launch_image_encode_tm(const float* mel_tm, const unsigned* max_keys, int keys_per_image, const float* clip_max_in, const float* thr,
+                                  uint8_t* img, float* clip_max_out, int N, int M, int Mpad, int T, int C, hipStream_t s) {
   hipLaunchKernelGGL(image_encode_tm_kernel, dim3((T + kEncTmT - 1) / kEncTmT, (M + kEncTmM - 1) / kEncTmM, N), dim3(256), 0, s, mel_tm,
-                     max_keys, clip_max_in, thr, img, clip_max_out, M, Mpad, T, C);
+                     max_keys, keys_per_image, clip_max_in, thr, img, clip_max_out, M, Mpad, T, C);
   return hipGetLastError();
 }
 hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s) {

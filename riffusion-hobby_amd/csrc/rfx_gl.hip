@@ -77,14 +77,11 @@ __global__ void __launch_bounds__(kThreads, RFX_MIN_WAVES) gl_iter_kernel(GlArgs
   const unsigned long long wg_t0 = wall_clock64(), wg_c0 = __builtin_readcyclecounter();  // 100 MHz wall clock, shader-clock counter
 #endif
 
-  // Run r of the launch's gridDim.x runs owns the frames [r N / R, (r + 1) N / R) of the batch's N = B T frames, counted clip
-  // after clip: every resident workgroup slot gets the same number of frames (+- 1) WHATEVER the batch size is (the host keeps
-  // R <= slots and every run at least 10 frames long).  A run that crosses a clip boundary is walked as one SEGMENT per clip;
-  // the segments of a clip belong to consecutive runs, so the two runs that share a hop block always differ in parity.
-  // (Until round 5 every clip was cut into ceil(slots / B) runs of its own: B = 65 launched 520 workgroups for 512 slots.)
-  // Round 5, second step: the runs are NOT equal any more - the workgroups dispatched first (one per CU) get longer runs than
-  // the ones that join them, by the ratio of the rates the pair was measured to run at (GlArgs::run_h / run_w1 / run_w2).
-  // Round 6: runs are whole groups of kGlGroup frames of a row (gl_run_start_frame), B T < 2^31 (checked by the host)
+  // The launch's rows (clip-channels) are cut into groups of kGlGroup frames; run r of the launch's gridDim.x runs owns a whole
+  // number of consecutive groups, counted row after row (gl_run_start_frame: the first N mod R runs one group more than the others -
+  // the workgroups dispatched first, which finish early; the host keeps R <= the chip's resident workgroup slots).  A run that
+  // crosses a row boundary is walked as one SEGMENT per row.  Which run a group falls into changes nothing in its arithmetic (the
+  // header comment): B T < 2^31 (checked by the host).
   const int gf_end = (int)gl_run_start_frame((long long)blockIdx.x + 1, gridDim.x, g.B, g.T, g.run_h, g.run_w1, g.run_w2);
   int gf = (int)gl_run_start_frame(blockIdx.x, gridDim.x, g.B, g.T, g.run_h, g.run_w1, g.run_w2);
   const int nblk = g.T - 1;  // hop blocks kept by istft's centre trim

@@ -144,10 +144,11 @@ struct StftMelArgs {
   const unsigned* pk_pad;  // [kQPad][2]: the thread's kMelPadsPerThread zero-padding byte addresses, two per word
   const unsigned* pk_seg;  // [Mpad][2]: {rising, falling} segment of filter m, each (first float << 4) | number of 16-byte reads
   // image_util.image_from_spectrogram's maximum (image_util.py:41) taken on the fly (rfx_image_from_waveform): when not null,
-  // max_keys[clip / max_group] receives an atomicMax of the order-preserving key (rfx_codec.hip::max_key) of every mel
-  // amplitude the launch forms; the launcher then leaves out the transpose to (B, M, T)
+  // max_keys[clip * chunks + chunk] receives the order-preserving key (rfx_codec.hip::max_key) of the largest mel amplitude the
+  // workgroup walking run `chunk` of row `clip` forms (chunks = ceil(T / frames_per_block); every word written exactly once per
+  // launch: no atomics, nothing to zero); the launcher then leaves out the transpose to (B, M, T)
   unsigned* max_keys;
-  int max_group;           // channels per image (1 mono, 2 stereo)
+  int max_group;           // (unused since round 6: an image's words are the C * chunks consecutive ones of its rows)
 };
 constexpr int kMelPadsPerThread = 4;
 // the kb (of a thread's 21 slots) that can contribute, as a compile-time set: 0x1F001F (kb 0..4 and 16..20) covers every bank that
@@ -380,8 +381,8 @@ hipError_t launch_image_encode(const float* mel, const float* clip_max, const fl
                                int C, hipStream_t s);
 // encode straight from the forward kernels' frame-major mel amplitudes [N*C][T][Mpad] (rfx_image_from_waveform): the transpose to the
 // image's (mel, time) order happens in LDS; the maximum comes as a key (max_keys, from the forward kernel) or as a float (clip_max)
-hipError_t launch_image_encode_tm(const float* mel_tm, const unsigned* max_keys, const float* clip_max_in, const float* thr, uint8_t* img,
-                                  float* clip_max_out, int N, int M, int Mpad, int T, int C, hipStream_t s);
+hipError_t launch_image_encode_tm(const float* mel_tm, const unsigned* max_keys, int keys_per_image, const float* clip_max_in, const float* thr,
+                                  uint8_t* img, float* clip_max_out, int N, int M, int Mpad, int T, int C, hipStream_t s);
 hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s);
 
 }  // namespace rfx

@@ -296,7 +296,8 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
 
   const int chunks = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   int clip = blockIdx.x / chunks;
-  int f0 = (blockIdx.x - clip * chunks) * a.frames_per_block;
+  int chunk = blockIdx.x - clip * chunks;  // index of this workgroup's run among the clip's `chunks` runs
+  int f0 = chunk * a.frames_per_block;
   int f1 = min(a.T, f0 + a.frames_per_block);
   if (a.run_skew > 0) {
     // Round 6: frames are independent here, so the runs need not be equal.  With exactly two workgroups per CU the blocks of the
@@ -311,6 +312,7 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
     const int c = idx - clip * hc, fl = a.frames_per_block + a.run_skew, fs = a.frames_per_block - a.run_skew;
     f0 = lng ? c * fl : hc * fl + c * fs;
     f1 = f0 + (lng ? fl : fs);
+    chunk = lng ? c : hc + c;
   }
   const rsrc_t xin = make_rsrc(a.wave + (size_t)clip * a.Lw, (size_t)a.Lw * 4);
   const rsrc_t win = make_rsrc(a.win, kWin * 4);
@@ -559,10 +561,20 @@ __global__ void __launch_bounds__(kThreads, 4) stft_mel2_kernel(StftMelArgs a) {
     }
     __syncthreads();  // the next frame's P1 overwrites the products
   }
-  if (a.max_keys) {  // image_from_spectrogram's maximum over the image's channels (image_util.py:41), see StftMelArgs::max_keys
+  if (a.max_keys) {  // image_from_spectrogram's maximum (image_util.py:41), see StftMelArgs::max_keys
+    // Round 6: one word per WORKGROUP, written exactly once per launch - no atomics, and no memset dispatch in front of the kernel;
+    // the encoder takes the maximum over an image's C * chunks words.
+    __shared__ unsigned wave_max[kWaves];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) runmax = max(runmax, (unsigned)__shfl_xor((int)runmax, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&a.max_keys[clip / a.max_group], runmax);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = runmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned m = wave_max[0];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) m = max(m, wave_max[w]);
+      a.max_keys[(size_t)clip * chunks + chunk] = m;
+    }
   }
 }
 

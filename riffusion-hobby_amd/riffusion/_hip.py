@@ -653,13 +653,13 @@ class Plan:
             pcm = out
         else:
             pcm = torch.empty((N, L, C), dtype=torch.int16, device=img.device)
-        peak = torch.zeros((N,), dtype=torch.float32, device=img.device)
         need = self.lib.rfx_audio_from_image_workspace_bytes(self.handle, N, int(stereo), W)
         ws = self._chk(workspace) if workspace is not None else None
         if ws is None or ws.numel() < need:
             with self._workspace(need) as borrowed:
                 return self.audio_from_image(img, stereo, lut, n_iter, momentum, seed, normalize, out=pcm, workspace=borrowed,
                                              clip_base=clip_base, magnitude_hint=magnitude_hint)
+        peak = torch.zeros((N,), dtype=torch.float32, device=img.device)
         opt = call_options(clip_base * C, magnitude_hint)
         check(self.lib.rfx_audio_from_image_u8_ex(self.handle, img.data_ptr(), N, W, int(stereo), lut.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, n_iter, momentum,
                                                   int(normalize), peak.data_ptr(), pcm.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(), ctypes.byref(opt)))
