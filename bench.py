@@ -805,7 +805,8 @@ def main():
         per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         elapsed = max(float(t.item()) for t in every)
     assert pcm.shape == (B, HOP * (T - 1), 1) and pcm.dtype == torch.int16 and int(pcm.abs().max()) > 30000
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_series = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]  # in order: a trend is the chip warming up, an outlier is not
+    per_step = sorted(step_series)
 
     # ---- roofline leg (outside the timed region): per-launch durations from HIP events on the stream
     roofline = None
@@ -913,6 +914,7 @@ def main():
             "ms_per_step_median": round(per_step[len(per_step) // 2], 3),
             "ms_per_step_max": round(per_step[-1], 3),
             "ms_per_step_max_over_min": round(per_step[-1] / per_step[0], 4),
+            "ms_per_step_series": [round(v, 3) for v in step_series],
             "shader_clock": clock.summary(),
             "higher_is_better": True,
             "scaling": "weak",
