@@ -80,6 +80,25 @@ def test_inverse_mel_is_exact_under_powers_of_two(plan, k):
     assert torch.equal((base[:, 1:4001] * f).view(torch.int32), scaled[:, 1:4001].view(torch.int32))
 
 
+def test_the_internal_exponents_do_not_show_in_the_result(plan):
+    """The same input with the scale taken from the data, from an exact hint and from hints 2^10 and 2^20 too large (other internal
+    exponents, the same arithmetic): InverseMelScale and Griffin-Lim return the same bits - the power of two commutes with every
+    rounding, which is the whole argument of the numeric-range contract."""
+    Tn = 40
+    mel = _mel(1e6, C=1, Tn=Tn)  # (largest amplitude below the hint's 30e6-style default on purpose)
+    spec0 = torch.rand(1, Tn, plan.n_stft, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = [plan.inverse_mel(mel.cuda(), 1, spec0=spec0, magnitude_hint=h) for h in (0.0, 1e6, 1e6 * 2.0 ** 10, 1e6 * 2.0 ** 20)]
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
+    S = outs[0]
+    a0 = plan.pack_complex(torch.view_as_complex(torch.rand(1, plan.n_stft, Tn, 2, generator=torch.Generator().manual_seed(3))).cuda())
+    waves = [plan.griffinlim(S, 1, Tn, 6, 0.99, angles0_slots=a0, magnitude_hint=h) for h in (0.0, 1e6, 1e6 * 2.0 ** 10, 1e6 * 2.0 ** 20)]
+    for w in waves[1:]:
+        assert torch.equal(w.view(torch.int32), waves[0].view(torch.int32))
+    fused = [plan.waveform_from_mel(mel.cuda(), 1, 6, 0.99, seed=5, magnitude_hint=h) for h in (0.0, 30e6)]
+    assert torch.equal(fused[0].view(torch.int32), fused[1].view(torch.int32))
+
+
 @pytest.mark.parametrize("max_value", MAX_VALUES + [1e30])
 def test_griffinlim_against_oracle_over_the_range(plan, O, max_value):
     """Griffin-Lim(4), injected phases, magnitudes of scale max_value: >= 95 dB vs the oracle (torch on the CPU takes |a| with
