@@ -106,7 +106,8 @@ class SpectrogramImageConverter:
         gather: T.Optional[str] = None,
         return_device: bool = False,
         validate: T.Optional[bool] = None,
-    ) -> T.Union[np.ndarray, torch.Tensor]:
+        return_range_flag: bool = False,
+    ) -> T.Union[np.ndarray, torch.Tensor, T.Tuple[torch.Tensor, torch.Tensor]]:
         """
         (N, H, W, 3) RGB tiles -> (n, samples, C) int16 PCM (or, with `return_waveform`, the (n, C, samples)
         float waveforms); a numpy array on the host, or with `return_device=True` a tensor that never left the GPU.
@@ -118,7 +119,9 @@ class SpectrogramImageConverter:
         computed on the device and read where the call synchronises anyway (the copy of the result to the
         host) - no host sync on the one-tile-per-request path; True: at once, with a host sync; False: never
         (`return_device=True` with a device input never synchronises and so cannot raise: there None turns a failed check
-        into an all-zero result - silence, not garbage audio - and attaches the device flag as `result.range_ok`).
+        into an all-zero result - silence, not garbage audio - and attaches the device flag as `result.range_ok`; with
+        `return_range_flag=True` the call returns `(result, range_ok)` instead, the flag as a value of its own: an attribute
+        does not survive slicing, `.to()` or a gather).
         Host tiles are uploaded chunk by chunk through pinned memory on a side stream (`batch_shard.ChunkSource`).
 
         `group`: a `torch.distributed` process group (or True for the default group).  Every rank
@@ -143,6 +146,8 @@ class SpectrogramImageConverter:
 
         if tiles_per_call < 1:
             raise ValueError(f"tiles_per_call must be >= 1, got {tiles_per_call}")
+        if return_range_flag and not return_device:
+            raise ValueError("return_range_flag goes with return_device=True (a host result raises on a failed range check instead)")
         if gather is None:
             gather = batch_shard.default_gather(group)
         if gather not in batch_shard.GATHER_MODES:
@@ -205,8 +210,9 @@ class SpectrogramImageConverter:
             # the flag travels with the result for a caller that wants to look: `result.range_ok`, a 0-dim bool tensor on the device
             # (True when nothing was checked: uint8 input, validate=False, or a check that already ran on the host).  It is a plain
             # attribute: slicing / .to() / a gather make a new tensor without it - read it from the tensor this call returned.
-            result.range_ok = range_ok if range_ok is not None else torch.ones((), dtype=torch.bool, device=result.device)
-            return result
+            flag = range_ok if range_ok is not None else torch.ones((), dtype=torch.bool, device=result.device)
+            result.range_ok = flag
+            return (result, flag) if return_range_flag else result
         if result.is_cuda:
             host = torch.empty(result.shape, dtype=result.dtype, pin_memory=True)  # gathered batch: one pinned copy
             host.copy_(result, non_blocking=True)

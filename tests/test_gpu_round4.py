@@ -249,6 +249,13 @@ def test_float_range_check_modes():
         assert dev.is_cuda and dev.shape == ref.shape and not bool(dev.range_ok) and int(dev.abs().max()) == 0
     dev = conv.audio_from_spectrogram_images(good.cuda(), seed=1, return_device=True)
     assert bool(dev.range_ok) and np.array_equal(dev.cpu().numpy(), ref)
+    # round 6: the flag as a return value of its own (an attribute is lost by the first slice), and always there
+    out, ok = conv.audio_from_spectrogram_images(bad.cuda(), seed=1, return_device=True, return_range_flag=True)
+    assert not bool(ok) and int(out.abs().max()) == 0 and not hasattr(out[:1], "range_ok")
+    out, ok = conv.audio_from_spectrogram_images(conv.quantize_pipeline_images(good).cuda(), seed=1, return_device=True, return_range_flag=True)
+    assert bool(ok) and bool(out.range_ok) and np.array_equal(out.cpu().numpy(), ref)   # uint8 input: nothing to check, flag True
+    with pytest.raises(ValueError, match="return_device"):
+        conv.audio_from_spectrogram_images(good, seed=1, return_range_flag=True)
 
 
 def test_plan_cache_returns_device_memory():

@@ -212,20 +212,30 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def test_the_rank_worker_itself_with_one_rank(tmp_path):
+    """The worker script of the 2-rank test below under `torch.distributed.run --nproc-per-node=1` (RCCL communicator with one
+    rank): runs on every box, so the script cannot rot while it waits for a second GPU."""
+    _run_ranks(tmp_path, 1)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL, one process per GPU)")
 def test_two_ranks_equal_one_rank_byte_for_byte(tmp_path):
     """clips sharded over two ranks, gather none / rank0 / all, equal the single-process result byte for byte."""
+    _run_ranks(tmp_path, 2)
+
+
+def _run_ranks(tmp_path, nproc):
     conv = _conv(True, iters=8)
     want = conv.audio_from_spectrogram_images(synthetic_tiles_u8(7, 512, 128, seed=12), seed=99)
     ref, script = tmp_path / "want.npy", tmp_path / "worker.py"
     np.save(ref, want)
     script.write_text(_WORKER)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script), ROOT, str(ref)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert res.stdout.count('"ok": true') == 2
+    assert res.stdout.count('"ok": true') == nproc
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL, one process per GPU)")
