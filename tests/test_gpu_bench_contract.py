@@ -73,9 +73,12 @@ def test_distributed_launch_one_rank_keeps_stdout_clean():
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "4",
-           "--no-cpu-baseline", "--no-forward"]
+           "--no-cpu-baseline", "--no-forward", "--n1-ms", "10.0"]
     d = _one_json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=600))
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4
+    # round 6: what an N > 1 line carries - every rank's own time (all_gather over RCCL) and, with --n1-ms, the weak-scaling figure
+    assert d["per_rank_ms"]["by_rank"] == [d["per_rank_ms"]["min"]] == [d["per_rank_ms"]["max"]] and d["vs_n1"]["n1_ms"] == 10.0
+    assert abs(d["vs_n1"]["speedup"] - 10.0 / d["ms_per_step"]) < 0.01 * d["vs_n1"]["speedup"] + 0.01
 
 
 def test_sharded_stereo_workload_small():
