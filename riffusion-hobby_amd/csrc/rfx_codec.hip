@@ -141,7 +141,9 @@ __global__ void __launch_bounds__(256) image_encode_tm_kernel(const float* __res
                                                              uint8_t* __restrict__ img, float* __restrict__ clip_max_out, int M,
                                                              int Mpad, int T, int C) {
   __shared__ float thr_s[256];
-  __shared__ __attribute__((aligned(16))) float tile[2][kEncTmM][kEncTmPitch];
+  // C tiles of dynamic LDS (round 6: a static [2] kept a mono launch at four workgroups per CU for a tile it never touches)
+  extern __shared__ __attribute__((aligned(16))) float tile_mem[];
+  float (*tile)[kEncTmM][kEncTmPitch] = reinterpret_cast<float (*)[kEncTmM][kEncTmPitch]>(tile_mem);
   thr_s[threadIdx.x] = threadIdx.x < 255 ? thr[threadIdx.x] : -__builtin_inff();
   const int t0 = blockIdx.x * kEncTmT, m0 = blockIdx.y * kEncTmM;
   const size_t n = blockIdx.z;
@@ -284,8 +286,8 @@ hipError_t launch_image_encode(const float* mel, const float* clip_max, const fl
 }
 hipError_t launch_image_encode_tm(const float* mel_tm, const unsigned* max_keys, int keys_per_image, const float* clip_max_in, const float* thr,
                                   uint8_t* img, float* clip_max_out, int N, int M, int Mpad, int T, int C, hipStream_t s) {
-  hipLaunchKernelGGL(image_encode_tm_kernel, dim3((T + kEncTmT - 1) / kEncTmT, (M + kEncTmM - 1) / kEncTmM, N), dim3(256), 0, s, mel_tm,
-                     max_keys, keys_per_image, clip_max_in, thr, img, clip_max_out, M, Mpad, T, C);
+  hipLaunchKernelGGL(image_encode_tm_kernel, dim3((T + kEncTmT - 1) / kEncTmT, (M + kEncTmM - 1) / kEncTmM, N), dim3(256),
+                     sizeof(float) * (size_t)C * kEncTmM * kEncTmPitch, s, mel_tm, max_keys, keys_per_image, clip_max_in, thr, img, clip_max_out, M, Mpad, T, C);
   return hipGetLastError();
 }
 hipError_t launch_pcm16(const float* wave, const float* clip_peak, int16_t* pcm, int N, int L, int C, int normalize, hipStream_t s) {
