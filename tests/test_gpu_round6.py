@@ -74,6 +74,36 @@ def test_other_engines_are_independent_of_chunking_too(rate):
     assert not np.array_equal(conv.audio_from_spectrogram_images(tiles, seed=12, tiles_per_call=5), whole)
 
 
+@pytest.mark.parametrize("B", [64, 32, 16])
+def test_forward_run_skew_changes_no_bit(B):
+    """The forward kernel's runs by dispatch order (StftMelArgs::run_skew: the first half of the grid walks longer runs) apply where
+    the launch is exactly two workgroups per CU - B x ceil(T / fpb) = 512: B = 64, 32, 16 at T = 512.  Frames are independent, so
+    the mel amplitudes, the image and its maximum must be what the same clips give in a batch one clip short (another launch shape:
+    equal runs), bit for bit."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import image_util
+
+    plan = _hip.get_plan(SpectrogramParams(), "cuda")
+    wave = torch.from_numpy((np.random.default_rng(B).standard_normal((B, 441 * 511)) * 8000).astype(np.float32)).cuda()
+    thr = torch.from_numpy(image_util.encode_thresholds(0.25)).cuda()
+    mel = plan.mel_from_waveform(wave)
+    ref = torch.cat([plan.mel_from_waveform(wave[: B - 1]), plan.mel_from_waveform(wave[B - 1:])])
+    assert torch.equal(mel.view(torch.int32), ref.view(torch.int32))
+    img, mx = plan.image_from_waveform(wave, False, thr)
+    img_a, mx_a = plan.image_from_waveform(wave[: B - 1], False, thr)
+    img_b, mx_b = plan.image_from_waveform(wave[B - 1:], False, thr)
+    assert torch.equal(img, torch.cat([img_a, img_b])) and torch.equal(mx, torch.cat([mx_a, mx_b]))
+    assert torch.equal(mx, mel.amax(dim=(1, 2)))  # the per-workgroup keys add up to the image's maximum
+    # stereo images: an image's maximum spans the keys of its two rows
+    if B == 64:
+        from riffusion.spectrogram_params import SpectrogramParams as P
+
+        plan2 = _hip.get_plan(P(stereo=True), "cuda")
+        img2, mx2 = plan2.image_from_waveform(wave[:32].contiguous(), True, thr)
+        assert torch.equal(mx2, mel[:32].reshape(16, 2, 512, 512).amax(dim=(1, 2, 3))) and img2.shape == (16, 512, 512, 3)
+
+
 def test_float_waveforms_are_independent_of_chunking():
     """return_waveform=True (decode, rfx_waveform_from_mel_ex per chunk): bit-identical float waveforms for 9 tiles in chunks of 9 / 4 / 1."""
     conv = _conv(False, iters=6)
