@@ -104,6 +104,24 @@ def test_forward_run_skew_changes_no_bit(B):
         assert torch.equal(mx2, mel[:32].reshape(16, 2, 512, 512).amax(dim=(1, 2, 3))) and img2.shape == (16, 512, 512, 3)
 
 
+def test_a_step_count_that_outgrows_64_kb_of_lds_falls_back_to_the_general_kernel():
+    """ADVICE r05: the line-form / group / wave SGD kernels take their loss history from dynamic LDS without the opt-in attribute;
+    a full-band bank with max_mel_iters = 2000 needs 72 KB there.  One function (imel_kernel_choice) now decides for the launcher,
+    rfx_plan_imel_kernel and the fused path alike: such a plan reports the general kernel (0) and runs on it; the same bank at
+    200 steps keeps its line-form kernel (5)."""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+
+    small = _hip.get_plan(SpectrogramParams(min_frequency=20, max_frequency=20000), "cuda")
+    big = _hip.get_plan(SpectrogramParams(min_frequency=20, max_frequency=20000, max_mel_iters=2000), "cuda")
+    assert small.lib.rfx_plan_imel_kernel(small.handle) == 5 and big.lib.rfx_plan_imel_kernel(big.handle) == 0
+    mel = torch.rand(1, 512, 6, generator=torch.Generator().manual_seed(1)).cuda() * 1e6
+    out = big.unpack_magnitudes(big.inverse_mel(mel, 1, seed=3), 1, 6)
+    assert bool(torch.isfinite(out).all()) and float(out.max()) > 0
+    wave = big.waveform_from_mel(torch.rand(1, 512, 30, generator=torch.Generator().manual_seed(2)).cuda() * 1e6, 1, 2, 0.99, seed=4)
+    assert wave.shape == (1, 441 * 29) and bool(torch.isfinite(wave).all())
+
+
 def test_float_waveforms_are_independent_of_chunking():
     """return_waveform=True (decode, rfx_waveform_from_mel_ex per chunk): bit-identical float waveforms for 9 tiles in chunks of 9 / 4 / 1."""
     conv = _conv(False, iters=6)
