@@ -122,6 +122,42 @@ def test_a_step_count_that_outgrows_64_kb_of_lds_falls_back_to_the_general_kerne
     assert wave.shape == (1, 441 * 29) and bool(torch.isfinite(wave).all())
 
 
+def test_one_tile_decode_can_be_captured_in_a_hip_graph():
+    """No entry point allocates, synchronises or touches host state once the plan exists, so the whole one-tile decode (75 launches)
+    records into a HIP graph and replays to the same bytes.  (It buys nothing - 1.054 ms replayed against 1.045 ms eager,
+    tools/probe_graph.py: the path is bound by its kernels, not by their launches - but a caller that captures its own pipeline
+    can include this call.)"""
+    from riffusion import _hip
+    from riffusion.spectrogram_params import SpectrogramParams
+    from riffusion.util import image_util
+
+    plan = _hip.get_plan(SpectrogramParams(num_griffin_lim_iters=8), "cuda")
+    tile = torch.from_numpy(synthetic_tiles_u8(1, 512, 128, seed=8)).cuda()
+    lut = plan.device_constant(("decode_lut", 0.25, 30e6), lambda: image_util.decode_lut(0.25, 30e6))
+    out = torch.empty((1, 441 * 127, 1), dtype=torch.int16, device="cuda")
+    ws = plan.audio_from_image_workspace(1, False, 128)
+
+    def call():
+        plan.audio_from_image(tile, False, lut, 8, 0.99, seed=7, out=out, workspace=ws, magnitude_hint=30e6)
+
+    call()
+    torch.cuda.synchronize()
+    ref = out.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for _ in range(2):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
 def test_float_waveforms_are_independent_of_chunking():
     """return_waveform=True (decode, rfx_waveform_from_mel_ex per chunk): bit-identical float waveforms for 9 tiles in chunks of 9 / 4 / 1."""
     conv = _conv(False, iters=6)
