@@ -108,7 +108,8 @@ typedef struct {
   uint32_t struct_size;
   int32_t gl_form;             /* rfx_gl_form */
   int32_t gl_frames_per_slot;  /* RFX_GL_FORM_AUTO takes the per-frame form up to this many frames per resident
-                                  workgroup slot of the chip (0 = default, 4: the measured crossover, 8 tiles per call) */
+                                  workgroup slot of the chip (0 = default, 6: the measured crossover - six 512-frame tiles per call;
+                                  4 until round 6) */
   int32_t frame_engine;        /* rfx_frame_engine */
   int32_t plan_layout;         /* rfx_plan_layout; added in round 4 - a caller built against the shorter struct gets AUTO */
   int32_t imel_form;           /* rfx_imel_form; added in round 4 after plan_layout, same rule */

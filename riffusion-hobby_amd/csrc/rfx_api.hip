@@ -126,7 +126,10 @@ struct rfx_plan {
   int fwd_run_cap = 64;            // longest run of frames one workgroup of the product-form kernel walks (RFX_FWD_RUN, read at creation)
   // generic-geometry path (rfx_generic.hip): everything but n_fft = 17640 / win = 4410 / hop = 441
   bool gl_latency_mode = true;     // small batches use the per-frame Griffin-Lim kernels (RFX_GL_LATENCY_MODE=0 disables)
-  int gl_latency_frames_per_slot = 4;  // ... up to this many frames per resident workgroup slot (RFX_GL_LATENCY_FRAMES)
+  int gl_latency_frames_per_slot = 6;  // ... up to this many frames per resident workgroup slot (RFX_GL_LATENCY_FRAMES).  4 until round 6;
+                                       // runs are whole groups of 16 frames now, so the run form costs a batch below nine tiles what it costs
+                                       // eight (3.4 - 3.7 ms per Griffin-Lim 32) and the per-frame form, linear in the batch, wins up to six
+                                       // tiles (3.2 ms): profiles/r06_griffinlim_forms_by_batch.txt
   int gl_form = RFX_GL_FORM_AUTO;      // rfx_plan_options.gl_form
   bool generic = false;
   GenGeom gg{};
@@ -324,7 +327,7 @@ int rfx_plan_create_ex(const rfx_params* params, const float* h_window, const fl
   // which Griffin-Lim device form a call takes: the options of rfx_plan_create_ex decide; the environment (read here, once)
   // only changes what RFX_GL_FORM_AUTO / the default threshold mean, for experiments
   if (const char* e = abl_env("RFX_GL_LATENCY_MODE")) pl->gl_latency_mode = atoi(e) != 0;
-  if (const char* e = abl_env("RFX_GL_LATENCY_FRAMES")) pl->gl_latency_frames_per_slot = atoi(e) > 0 ? atoi(e) : 4;
+  if (const char* e = abl_env("RFX_GL_LATENCY_FRAMES")) pl->gl_latency_frames_per_slot = atoi(e) > 0 ? atoi(e) : 6;
   pl->gl_form = opt.gl_form;
   if (opt.gl_frames_per_slot > 0) pl->gl_latency_frames_per_slot = opt.gl_frames_per_slot;
 #if defined(RFX_TIMING) || defined(RFX_WGCLOCK)
