@@ -914,7 +914,14 @@ int rfx_stft(const rfx_plan* plan, const float* d_wave, int B, int Lw, float* d_
 static bool gl_use_latency_mode(const rfx_plan* plan, int B, int T) {
   if (plan->gl_form == RFX_GL_FORM_RUNS) return false;
   if (plan->gl_form == RFX_GL_FORM_FRAMES) return true;
-  return plan->gl_latency_mode && (long long)B * T <= (long long)plan->gl_latency_frames_per_slot * plan->num_cus * plan->gl_wgs_per_cu;
+  if (!plan->gl_latency_mode) return false;
+  const long long nframes = (long long)B * T, slots = (long long)plan->num_cus * plan->gl_wgs_per_cu;
+  if (nframes <= (long long)plan->gl_latency_frames_per_slot * slots) return true;
+  // one stair further (round 6): as soon as the batch has more groups than the chip has CUs some CU walks two 16-frame runs and the
+  // launch lasts as long as if all did (5.6 ms per Griffin-Lim 32 for nine tiles, 3.7 for eight); the per-frame form still beats
+  // that up to ten frames per slot (5.0 / 5.2 ms for nine / ten tiles: profiles/r06_griffinlim_forms_by_batch.txt)
+  const long long groups = (long long)B * rfx::gl_groups_per_row(T);
+  return groups > plan->num_cus && groups <= slots && 3 * nframes <= 5LL * plan->gl_latency_frames_per_slot * slots;
 }
 
 // The runs of one launch of the run-based Griffin-Lim kernel: at most one run per resident workgroup slot of the chip (a launch of
